@@ -1,0 +1,136 @@
+/* voxcarve.h -- C ABI of libvoxcarve.so, the MI355X (gfx950) visual-hull carve engine.
+ *
+ * Drop-in boundary for ONE path of ChristosP1/Voxel-Based-3D-Reconstruction: the
+ * per-voxel x per-camera projection-and-mask test behind set_voxel_positions().
+ * The reference is pure Python; a maintainer binds this library with ctypes (stub in
+ * INTEGRATION.md).  Each entry point names the reference interface it replaces
+ * (paths relative to the reference root).
+ *
+ * Conventions: every function returns 0 (VC_OK) or a negative vc_status; the message
+ * of the last failure is vc_last_error(ctx).  A context owns one HIP device + stream
+ * and all device buffers; it is NOT thread-safe (the reference calls the path from one
+ * thread, executable.py:182-188).  Host buffers belong to the caller.  An empty
+ * result is count 0, not an error (reference returns [], []).
+ *
+ * Voxel numbering (voxel_reconstruction.py:52-57): linear index
+ *     i = iz*nx*ny + ix*ny + iy,   centre = (xs[ix], ys[iy], zs[iz]),
+ * axes = np.linspace(lo, hi, n).  Survivor lists are ascending in i, which is the
+ * order the reference's dicts yield (assignment.py:121-133).
+ */
+#ifndef VOXCARVE_H
+#define VOXCARVE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vc_ctx vc_ctx;
+
+typedef enum {
+    VC_OK = 0,
+    VC_ERR_ARG = -1,    /* bad argument / call order */
+    VC_ERR_HIP = -2,    /* HIP runtime error (message has hipGetErrorString) */
+    VC_ERR_RCCL = -3,   /* RCCL missing or failed */
+    VC_ERR_OOM = -4,    /* device allocation failed */
+    VC_ERR_NODEV = -5   /* no usable GPU: there is NO CPU fallback */
+} vc_status;
+
+typedef enum {
+    VC_MODE_FUSED = 0,  /* project in-kernel (fp64), nothing precomputed            */
+    VC_MODE_LUT = 1     /* stream the packed int32 LUT built by vc_build_lut()      */
+} vc_mode;
+
+enum {
+    VC_FLAG_VIEWMASK = 1u  /* also keep the per-voxel camera bitmask (compat dicts) */
+};
+
+#define VC_MAX_CAMERAS 16
+#define VC_UNIQUE_ID_BYTES 128
+
+typedef struct {
+    float carve_ms;     /* the carve kernel alone (HIP events on the context's stream) */
+    float compact_ms;   /* scan + emit kernels                                         */
+    float gather_ms;    /* RCCL all-gather (vc_allgather)                              */
+    float lut_ms;       /* last vc_build_lut                                           */
+    float h2d_ms;       /* last vc_upload_masks / vc_upload_frame incl. bit-packing    */
+    uint64_t voxels;    /* voxels of this rank's slab                                  */
+    uint64_t survivors; /* survivors of the last carve (this rank)                     */
+    uint32_t carve_launches; /* carve kernel launches since vc_timing_reset            */
+    float carve_ms_sum; /* summed carve kernel time since vc_timing_reset              */
+} vc_timing_t;
+
+/* ---- lifetime ------------------------------------------------------------------ */
+int vc_device_count(int *n_out);
+int vc_create(int device, vc_ctx **out);
+int vc_destroy(vc_ctx *ctx);
+const char *vc_last_error(const vc_ctx *ctx);      /* ctx may be NULL: last create error */
+int vc_synchronize(vc_ctx *ctx);
+
+/* ---- geometry: replaces create_voxel_volume, voxel_reconstruction.py:35-59 ------ */
+/* bounds = {x_min,x_max,y_min,y_max,z_min,z_max}.  No point array is materialised:
+ * kernels regenerate the np.linspace coordinates from the index. */
+int vc_set_grid(vc_ctx *ctx, uint32_t nx, uint32_t ny, uint32_t nz, const double bounds[6]);
+/* This rank's block of the grid: iz in [z0, z1) (multi-GPU z-slab split).  Default all. */
+int vc_set_slab(vc_ctx *ctx, uint32_t z0, uint32_t z1);
+/* The three np.linspace axes as the device uses them (tests; out arrays of nx, ny, nz). */
+int vc_get_axes(vc_ctx *ctx, double *xs, double *ys, double *zs);
+
+/* ---- cameras: replaces load_config_info, voxel_reconstruction.py:10-32 ---------- */
+/* K9: [C,9] row-major camera matrices; dist5: [C,5] (k1,k2,p1,p2,k3); R9: [C,9] rotation
+ * matrices (host does Rodrigues so fixtures pin R); t3: [C,3]; H, W: mask size. */
+int vc_set_cameras(vc_ctx *ctx, uint32_t n_cameras, const double *K9, const double *dist5,
+                   const double *R9, const double *t3, uint32_t H, uint32_t W);
+
+/* ---- per-frame inputs: the fg_masks / images arguments of ------------------------
+ *      update_visible_voxels_and_extract_colors, voxel_reconstruction.py:89 --------- */
+/* masks: u8 [C,H,W], foreground where > 0 (line 112).  Bit-packed on the device.
+ * slot selects one of the resident frame sets (0..n-1, created on first use). */
+int vc_upload_masks(vc_ctx *ctx, uint32_t slot, const uint8_t *masks);
+/* bgr: u8 [H,W,3] image of camera cam (0-based) for colour sampling (lines 119-122). */
+int vc_upload_frame(vc_ctx *ctx, uint32_t slot, uint32_t cam, const uint8_t *bgr);
+
+/* ---- lookup table: replaces create_lookup_table, voxel_reconstruction.py:62-86 --- */
+/* Projects this rank's slab once into int32 [C][n]: int(y)*W + int(x), or -1 when the
+ * float coordinates fail the bounds test of line 110.  Needed by VC_MODE_LUT only. */
+int vc_build_lut(vc_ctx *ctx);
+int vc_fetch_lut(vc_ctx *ctx, uint32_t cam, int32_t *out);   /* n entries (tests) */
+/* Device projection of arbitrary points with camera cam: uv = [n,2] float64 (tests). */
+int vc_project(vc_ctx *ctx, uint32_t cam, const double *xyz, uint64_t n, double *uv);
+
+/* ---- the hot path: replaces update_visible_voxels_and_extract_colors (:89-124) ----
+ *      plus the selection loop of set_voxel_positions, assignment.py:116-133 -------- */
+/* Keeps voxels seen by >= min_views cameras (reference: 4 of 4).  color_cam is the
+ * 0-based camera whose image colours the survivors (reference key 2 -> index 1), or
+ * -1 for none.  Leaves the ordered survivor records on the device; *n_out = count. */
+int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int mode,
+             uint32_t flags, uint64_t *n_out);
+/* Survivors of the last carve: idx u32 [S] (global linear index, ascending), rgb u8 [S,3]
+ * (RGB order, i.e. the reference's BGR[::-1]) and seen u8 [S] (1 if the colour camera
+ * sees the voxel -- the reference raises KeyError when it does not).  Any may be NULL. */
+int vc_fetch(vc_ctx *ctx, uint32_t *idx, uint8_t *rgb, uint8_t *seen);
+/* Raw 8-byte records {u32 idx, u8 r, g, b, seen} of the last carve (S of them). */
+int vc_fetch_records(vc_ctx *ctx, uint64_t *records);
+/* Per-voxel camera bitmask u16 [n] of the last carve run with VC_FLAG_VIEWMASK. */
+int vc_fetch_viewmask(vc_ctx *ctx, uint16_t *viewmask);
+/* Dense occupancy of the last carve: ceil(n/64)*8 bytes, bit (j & 7) of byte j >> 3 for
+ * slab-local voxel j (consumer shape of assignment.py:143-146). */
+int vc_fetch_occupancy(vc_ctx *ctx, uint8_t *bits);
+
+int vc_timing(vc_ctx *ctx, vc_timing_t *out);
+int vc_timing_reset(vc_ctx *ctx);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI (no reference counterpart) ---- */
+int vc_comm_unique_id(uint8_t out[VC_UNIQUE_ID_BYTES]);
+int vc_comm_init(vc_ctx *ctx, int n_ranks, int rank, const uint8_t uid[VC_UNIQUE_ID_BYTES]);
+int vc_comm_destroy(vc_ctx *ctx);
+/* All-gather of every rank's survivor records in rank (= z-slab = index) order.
+ * counts_out (NULL ok): n_ranks entries.  *total_out = global survivor count. */
+int vc_allgather(vc_ctx *ctx, uint64_t *counts_out, uint64_t *total_out);
+int vc_fetch_gathered(vc_ctx *ctx, uint64_t *records);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOXCARVE_H */

@@ -1,0 +1,287 @@
+"""Parity of the HIP path (through the C ABI) with the oracle.  Needs an MI355X.
+
+Bar: BIT-EXACT for everything (indices, order, colours, camera bitmasks, LUT offsets and
+the float64 projected coordinates themselves).  Small grids are compared element by
+element with the oracle and the committed goldens; BASELINE.json's full sizes are covered
+by size-independent properties (mode agreement, slab-split invariance, idempotence,
+ordering, occupancy/record consistency)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import fixtures_util as fx
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng(built):
+    import voxcarve
+    e = voxcarve.CarveEngine(0)
+    yield e
+    e.close()
+
+
+def setup_real(eng, cams, masks, frames, grid):
+    eng.set_grid(*grid)
+    eng.set_cameras(cams, *masks[0].shape)
+    eng.upload_masks(masks)
+    for c, f in enumerate(frames):
+        eng.upload_frame(c, f)
+
+
+def test_axes_are_numpy_linspace(eng):
+    for grid in ((64, 64, 64), (3, 1, 1000), (1, 2, 1), (1024, 513, 7)):
+        eng.set_grid(*grid)
+        xs, ys, zs = eng.axes()
+        assert np.array_equal(xs, np.linspace(-512, 1024, num=grid[0]))
+        assert np.array_equal(ys, np.linspace(-1024, 1024, num=grid[1]))
+        assert np.array_equal(zs, np.linspace(-2048, 512, num=grid[2]))
+
+
+def test_device_projection_bits_equal_oracle(eng, cams, masks):
+    """float64 (u, v) out of the kernel == the numpy restatement, bit for bit."""
+    from oracle import carve_np
+    g = json.load(open(os.path.join(fx.GOLDEN, "projected_samples.json")))
+    pts = carve_np.points_of_indices(np.array(g["idx"]), *g["grid"])
+    rng = np.random.default_rng(3)
+    extra = np.concatenate([pts, rng.uniform(-3000, 3000, (20000, 3)),
+                            np.array([[0.0, 0.0, 0.0], [1e6, -1e6, 1e6], [1e300, 1.0, 1.0]])])
+    eng.set_grid(8, 8, 8)
+    eng.set_cameras(cams, *masks[0].shape)
+    for c, cam in enumerate(cams):
+        want = np.array([float.fromhex(h) for h in g["uv"][c]]).reshape(-1, 2)
+        assert np.array_equal(eng.project(c, pts), want)
+        got = eng.project(c, extra)
+        ref = carve_np.project_points(extra, cam.R, cam.tvec, cam.K, cam.dist)
+        fin = np.isfinite(ref).all(axis=1)
+        assert np.array_equal(got[fin], ref[fin])
+        assert np.array_equal(carve_np.pixel_offsets(got, 486, 644), carve_np.pixel_offsets(ref, 486, 644))
+
+
+def test_projection_with_zero_depth_and_behind_camera(eng):
+    from voxcarve.camera import Camera
+    from oracle import carve_np
+    cam = Camera(np.array([[50, 0, 20], [0, 50, 20], [0, 0, 1.0]]), np.zeros(5), np.zeros(3), np.zeros(3))
+    pts = np.array([[1.0, 2.0, 0.0], [0.1, 0.1, -1.0], [0.0, 0.0, 5.0], [0.0, 0.0, 0.0], [1e-320, 0, 1e-320]])
+    eng.set_grid(2, 2, 2)
+    eng.set_cameras([cam], 40, 40)
+    got = eng.project(0, pts)
+    ref = carve_np.project_points(pts, cam.R, cam.tvec, cam.K, cam.dist)
+    assert np.array_equal(got, ref)          # includes the z == 0 branch and denormals
+
+
+@pytest.mark.parametrize("n", [64, 128])
+def test_carve_matches_golden_both_modes(eng, cams, masks, frames, n):
+    idx_want, bgr_want, summary = fx.expected(n)
+    setup_real(eng, cams, masks, frames, (n, n, n))
+    eng.build_lut()
+    lut = np.stack([eng.fetch_lut(c) for c in range(4)])
+    assert hashlib.sha256(lut.tobytes()).hexdigest() == summary["offsets_sha256"]
+    for mode in ("fused", "lut"):
+        count = eng.carve(mode=mode)
+        idx, rgb, seen = eng.fetch()
+        assert count == summary["survivors"]
+        assert np.array_equal(idx, idx_want), mode
+        assert np.array_equal(rgb[:, ::-1], bgr_want), mode
+        assert seen.all()
+        eng.carve(mode=mode, viewmask=True, min_views=1, color_cam=None)
+        vm = eng.fetch_viewmask()
+        assert hashlib.sha256(vm.tobytes()).hexdigest() == summary["viewmask_sha256"], mode
+        assert eng.count == summary["any_view"]
+        occ = eng.fetch_occupancy()
+        assert np.array_equal(np.nonzero(occ)[0], np.nonzero(vm)[0])
+
+
+def test_config2_256_cubed_bit_exact_vs_oracle(eng, cams, masks, frames):
+    """BASELINE config 2: 256^3, 4 real cameras, occupancy bit-exact vs the CPU path."""
+    from oracle import carve_c
+    want = carve_c.carve(256, 256, 256, fx.oracle_cams(cams), masks, frames)
+    assert want["count"] == 461113                                   # SURVEY probe count
+    setup_real(eng, cams, masks, frames, (256, 256, 256))
+    eng.build_lut()
+    for mode in ("fused", "lut"):
+        assert eng.carve(mode=mode) == want["count"]
+        idx, rgb, seen = eng.fetch()
+        assert np.array_equal(idx, want["idx"]) and np.array_equal(rgb[:, ::-1], want["bgr"]) and seen.all()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_scenes_ragged_shapes(eng, seed):
+    """Random cameras/masks; grids with ny not a multiple of 64, H*W not a multiple of 32."""
+    from oracle import carve_c
+    C = 1 + seed % 5
+    cams, masks, frames = fx.random_scene(seed, C=C, H=37 + seed, W=53)
+    grid = [(9, 17, 11), (16, 64, 5), (1, 1, 1), (7, 128, 3), (33, 3, 2), (5, 65, 9), (2, 192, 2), (64, 1, 64)][seed]
+    eng.set_grid(*grid)
+    eng.set_cameras(cams, *masks[0].shape)
+    eng.upload_masks(masks)
+    cc = seed % C
+    eng.upload_frame(cc, frames[cc])
+    eng.build_lut()
+    oc = fx.oracle_cams(cams)
+    for mv in sorted({1, max(1, C - 1), C}):
+        want = carve_c.carve(*grid, oc, masks, frames, min_views=mv, color_cam=cc, want_viewmask=True, want_lut=True)
+        for c in range(C):
+            assert np.array_equal(eng.fetch_lut(c), want["offsets"][c])
+        for mode in ("fused", "lut"):
+            for vm_flag in (False, True):
+                assert eng.carve(min_views=mv, color_cam=cc, mode=mode, viewmask=vm_flag) == want["count"]
+                idx, rgb, seen = eng.fetch()
+                assert np.array_equal(idx, want["idx"])
+                seen_want = ((want["viewmask"][want["idx"]] >> cc) & 1).astype(bool)
+                assert np.array_equal(seen, seen_want)
+                assert np.array_equal(rgb[:, ::-1], want["bgr"])
+                if vm_flag:
+                    assert np.array_equal(eng.fetch_viewmask(), want["viewmask"])
+
+
+def test_all_background_and_all_foreground(eng, cams, masks):
+    from oracle import carve_c
+    H, W = masks[0].shape
+    eng.set_grid(32, 64, 32)
+    eng.set_cameras(cams, H, W)
+    eng.upload_masks([np.zeros((H, W), np.uint8)] * 4)
+    assert eng.carve(color_cam=None) == 0
+    idx, rgb, seen = eng.fetch()
+    assert idx.size == 0 and rgb.shape == (0, 3)
+    ones = [np.full((H, W), 1, np.uint8)] * 4          # any value > 0 is foreground
+    eng.upload_masks(ones)
+    want = carve_c.carve(32, 64, 32, fx.oracle_cams(cams), ones)
+    assert eng.carve(color_cam=None) == want["count"] > 0
+    assert np.array_equal(eng.fetch()[0], want["idx"])
+
+
+def test_simulated_slab_split_equals_full_grid(eng, cams, masks, frames):
+    """G-way z-split run slab by slab on one GPU: rank-ordered concatenation == full result."""
+    from voxcarve import slabs
+    grid = (64, 64, 64)
+    setup_real(eng, cams, masks, frames, grid)
+    eng.carve()
+    full = eng.fetch_records()
+    for G in (2, 3, 8):
+        parts = []
+        for r in range(G):
+            slabs.carve_slab(eng, grid, G, r)
+            parts.append(eng.fetch_records())
+        assert np.array_equal(slabs.merge_rank_lists(parts), full), G
+    eng.set_slab(0, 64)
+    eng.set_slab(5, 5)                                  # empty slab
+    assert eng.carve() == 0
+
+
+def test_rccl_allgather_single_rank(eng, cams, masks, frames):
+    """The RCCL path (dlopen, communicator, counts all-gather, grouped broadcast) with one rank."""
+    import voxcarve
+    setup_real(eng, cams, masks, frames, (64, 64, 64))
+    n = eng.carve()
+    uid = voxcarve.CarveEngine.comm_unique_id()
+    eng.comm_init(1, 0, uid)
+    counts, total = eng.allgather()
+    assert counts.tolist() == [n] and total == n
+    assert np.array_equal(eng.fetch_gathered(), eng.fetch_records())
+    eng.comm_destroy()
+
+
+def test_drop_in_module_surface(built, cams, masks, frames):
+    """voxcarve.voxel_reconstruction keeps the reference's names and dict-shaped returns."""
+    from voxcarve import voxel_reconstruction as vr
+    from oracle import carve_literal, carve_np
+    n, half = 24, 12
+    vol = vr.create_voxel_volume(n, half * 2, n)
+    table = vr.create_lookup_table(vol, 4, os.path.join(fx.GOLDEN, "data"), "config.xml")
+    visible, colors = vr.update_visible_voxels_and_extract_colors(table, masks, frames)
+    # R from the product's own host-side Rodrigues (its parity has its own test, with an ulp band)
+    ocams = fx.oracle_cams(table.cameras)
+    lit_table = carve_literal.build_lookup_table(carve_np.create_voxel_volume(n, half * 2, n), ocams)
+    lit_visible, lit_colors = carve_literal.visible_voxels_and_colors(lit_table, masks, frames)
+    assert list(visible.items()) == list(lit_visible.items())             # same keys, order and views
+    assert list(colors.keys()) == list(lit_colors.keys())
+    for k in colors:
+        assert list(colors[k].keys()) == list(lit_colors[k].keys())
+        for cam_key in colors[k]:
+            assert np.array_equal(colors[k][cam_key], lit_colors[k][cam_key])
+    # the reference's own selection loop (assignment.py:116-133) runs unchanged on these dicts
+    data, cols = carve_literal.select_for_viewer(visible, colors)
+    want_data, want_cols = carve_literal.select_for_viewer(lit_visible, lit_colors)
+    assert data == want_data and all(np.array_equal(a, b) for a, b in zip(cols, want_cols))
+    table.engine.close()
+
+
+def test_set_voxel_positions_drop_in(built, cams, masks, frames):
+    from voxcarve import assignment
+    from oracle import carve_literal
+    src = assignment.StaticFrameSource([(frames, masks)])
+    for mode in ("fused", "lut"):
+        assignment.configure(frame_source=assignment.StaticFrameSource([(frames, masks)]),
+                             data_path=os.path.join(fx.GOLDEN, "data"), mode=mode)
+        pos, col = assignment.set_voxel_positions(32, 16, 32)
+        from voxcarve.camera import load_cameras
+        file_cams = load_cameras(os.path.join(fx.GOLDEN, "data"), 4)
+        data, cols = carve_literal.set_voxel_positions(32, 16, 32, fx.oracle_cams(file_cams), masks, frames)
+        assert pos.dtype == np.float32 and pos.shape == (len(data), 3) and len(pos) == len(col)
+        assert np.array_equal(pos, np.array(data, dtype=np.float32))      # what mesh.py:82 would build
+        assert np.array_equal(col, np.array(cols, dtype=np.float32))
+        assert assignment.set_voxel_positions(32, 16, 32) == ([], [])     # end of video
+    assignment.configure(frame_source=src)
+    del src
+
+
+def test_error_paths_raise(eng, cams, masks):
+    from voxcarve._lib import VoxcarveError
+    eng.set_grid(8, 8, 8)
+    eng.set_cameras(cams, *masks[0].shape)
+    with pytest.raises(VoxcarveError, match="no masks"):
+        eng.carve(slot=5)
+    eng.upload_masks(masks)
+    with pytest.raises(VoxcarveError, match="vc_build_lut"):
+        eng.carve(mode="lut")
+    with pytest.raises(VoxcarveError):
+        eng.set_grid(0, 8, 8)
+    with pytest.raises(VoxcarveError):
+        eng.set_grid(4096, 4096, 4096)
+    with pytest.raises(VoxcarveError):
+        eng.set_slab(3, 99)
+    with pytest.raises(ValueError):
+        eng.upload_masks(masks[:2])
+
+
+def test_full_size_1024_properties(eng, cams, masks, frames):
+    """BASELINE config 3 size (1024^3 x 4): properties that need no CPU run of that size."""
+    from voxcarve import slabs
+    from oracle import carve_c
+    grid = (1024, 1024, 1024)
+    setup_real(eng, cams, masks, frames, grid)
+    n = eng.carve(mode="fused")
+    rec = eng.fetch_records()
+    idx = rec.astype(np.uint32)
+    assert n == rec.size and n > 0
+    assert np.all(idx[1:] > idx[:-1])                                   # strictly ascending
+    digest = hashlib.sha256(rec.tobytes()).hexdigest()
+    assert eng.carve(mode="fused") == n                                 # idempotent
+    assert hashlib.sha256(eng.fetch_records().tobytes()).hexdigest() == digest
+    # an oracle run over two thin z-slabs of the full-size grid pins the values themselves
+    for z0 in (300, 511):
+        i0, i1 = z0 * 1024 * 1024, (z0 + 2) * 1024 * 1024
+        want = carve_c.carve(*grid, fx.oracle_cams(cams), masks, frames, index_range=(i0, i1))
+        sel = (idx >= i0) & (idx < i1)
+        assert np.array_equal(idx[sel], want["idx"])
+        assert np.array_equal(rec[sel].view(np.uint8).reshape(-1, 8)[:, 4:7][:, ::-1], want["bgr"])
+    # 8-way slab split (BASELINE config 4) concatenates to the same list
+    parts = []
+    for r in range(8):
+        slabs.carve_slab(eng, grid, 8, r)
+        parts.append(eng.fetch_records())
+    assert hashlib.sha256(slabs.merge_rank_lists(parts).tobytes()).hexdigest() == digest
+    # LUT mode on one slab (the table for the whole grid is 17 GB; a quarter is plenty here)
+    eng.set_slab(256, 512)
+    eng.build_lut()
+    a = eng.carve(mode="lut")
+    ra = eng.fetch_records()
+    assert eng.carve(mode="fused") == a and np.array_equal(eng.fetch_records(), ra)
+    i0 = 256 * 1024 * 1024
+    sel = (idx >= i0) & (idx < 2 * i0)
+    assert np.array_equal(ra, rec[sel])

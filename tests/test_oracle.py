@@ -1,0 +1,133 @@
+"""The oracle against the committed fixtures, and its three restatements against each other.
+
+Parity vs OpenCV itself is UNPINNED (cv2 absent, reference has no golden vectors): these
+tests pin the oracle to (a) the reference's data files and (b) agreement of independent
+restatements.  Reference lines: voxel_reconstruction.py:35-124, assignment.py:116-133."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import fixtures_util as fx
+from oracle import carve_c, carve_literal, carve_np
+
+
+def test_config_xml_matches_golden_hex(cams):
+    g = json.load(open(os.path.join(fx.GOLDEN, "cameras.json")))
+    for c in range(4):
+        K, dist, rvec, tvec = carve_np.read_config_xml(os.path.join(fx.GOLDEN, "data", "cam%d" % (c + 1), "config.xml"))
+        gc = g["cameras"][c]
+        assert [float(v).hex() for v in K.reshape(-1)] == gc["K"]
+        assert [float(v).hex() for v in dist.reshape(-1)] == gc["dist"]
+        assert [float(v).hex() for v in rvec.reshape(-1)] == gc["rvec"]
+        assert [float(v).hex() for v in tvec.reshape(-1)] == gc["tvec"]
+        assert K.shape == (3, 3) and dist.shape == (1, 5) and rvec.shape == (3, 1) and tvec.shape == (3, 1)
+
+
+def test_rodrigues_is_a_rotation_and_matches_golden(cams):
+    g = json.load(open(os.path.join(fx.GOLDEN, "cameras.json")))
+    for c, cam in enumerate(cams):
+        R = carve_np.rodrigues(cam.rvec)
+        want = np.array([float.fromhex(h) for h in g["cameras"][c]["R"]]).reshape(3, 3)
+        # libm sin/cos may differ by an ulp between hosts; the carve tests use the pinned R
+        assert np.max(np.abs(R - want)) <= 2 * np.finfo(np.float64).eps
+        assert np.allclose(R @ R.T, np.eye(3), atol=1e-14) and abs(np.linalg.det(R) - 1) < 1e-14
+    assert np.array_equal(carve_np.rodrigues(np.zeros(3)), np.eye(3))
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 64, 100, 128, 1000, 1024])
+def test_c_axis_equals_numpy_linspace(built, n):
+    for lo, hi in ((-512, 1024), (-1024, 1024), (-2048, 512), (0.1, 0.7), (5, 5), (3, -9)):
+        assert np.array_equal(carve_c.axis(lo, hi, n), np.linspace(lo, hi, num=n)), (lo, hi, n)
+
+
+def test_voxel_order_matches_meshgrid_form():
+    pts = carve_np.create_voxel_volume(5, 7, 3)
+    idx = np.arange(5 * 7 * 3)
+    assert np.array_equal(pts, carve_np.points_of_indices(idx, 5, 7, 3))
+    # i = iz*nx*ny + ix*ny + iy, y fastest
+    xs, ys, zs = carve_np.axis_tables(5, 7, 3)
+    assert np.array_equal(pts[1], [xs[0], ys[1], zs[0]]) and np.array_equal(pts[7], [xs[1], ys[0], zs[0]])
+    assert np.array_equal(pts[35], [xs[0], ys[0], zs[1]])
+
+
+def test_projected_samples_golden(built, cams):
+    g = json.load(open(os.path.join(fx.GOLDEN, "projected_samples.json")))
+    pts = carve_np.points_of_indices(np.array(g["idx"]), *g["grid"])
+    for c, cam in enumerate(cams):
+        want = np.array([float.fromhex(h) for h in g["uv"][c]]).reshape(-1, 2)
+        got = carve_np.project_points(pts, cam.R, cam.tvec, cam.K, cam.dist)
+        assert np.array_equal(got, want)
+        assert np.array_equal(carve_c.project(pts, (cam.K, cam.dist, cam.R, cam.tvec)), want)
+
+
+@pytest.mark.parametrize("n", [64, 128])
+def test_carve_matches_golden(built, cams, masks, frames, n):
+    idx, bgr, summary = fx.expected(n)
+    assert idx.size == summary["survivors"] == {64: 6981, 128: 57048}[n]   # SURVEY probe counts
+    assert hashlib.sha256(idx.tobytes()).hexdigest() == summary["idx_sha256"]
+    oc = fx.oracle_cams(cams)
+    res = carve_np.carve(n, n, n, oc, masks, frames)
+    assert np.array_equal(res["idx"], idx) and np.array_equal(res["bgr"], bgr)
+    assert hashlib.sha256(res["viewmask"].tobytes()).hexdigest() == summary["viewmask_sha256"]
+    assert hashlib.sha256(res["offsets"].tobytes()).hexdigest() == summary["offsets_sha256"]
+    resc = carve_c.carve(n, n, n, oc, masks, frames, want_viewmask=True, want_lut=True)
+    assert np.array_equal(resc["idx"], idx) and np.array_equal(resc["bgr"], bgr)
+    assert np.array_equal(resc["viewmask"], res["viewmask"]) and np.array_equal(resc["offsets"], res["offsets"])
+    assert int((res["viewmask"] != 0).sum()) == summary["any_view"]
+
+
+def test_literal_dict_restatement_agrees(built, cams, masks, frames):
+    """The dict/loop mirror of the reference's Python gives the numpy oracle's list, in order."""
+    n, half = 24, 12
+    data, cols = carve_literal.set_voxel_positions(n, half, n, fx.oracle_cams(cams), masks, frames)
+    res = carve_np.carve(n, 2 * half, n, fx.oracle_cams(cams), masks, frames)
+    assert len(data) == res["idx"].size > 0
+    keys = carve_np.voxel_keys(res["idx"], n, 2 * half, n)
+    assert np.array_equal(np.array(data), carve_np.viewer_positions(keys))
+    assert np.array_equal(np.array(cols), carve_np.viewer_colors(res["bgr"]))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_numpy_vs_c_on_random_scenes(built, seed):
+    cams, masks, frames = fx.random_scene(seed, C=1 + seed % 4)
+    oc = fx.oracle_cams(cams)
+    nx, ny, nz = 9 + seed, 64 if seed % 2 else 17, 11
+    for mv in (1, len(cams)):
+        a = carve_np.carve(nx, ny, nz, oc, masks, frames, min_views=mv, color_cam=0)
+        b = carve_c.carve(nx, ny, nz, oc, masks, frames, min_views=mv, color_cam=0, want_viewmask=True, want_lut=True)
+        assert np.array_equal(a["idx"], b["idx"]) and np.array_equal(a["viewmask"], b["viewmask"])
+        assert np.array_equal(a["offsets"], b["offsets"]) and np.array_equal(a["bgr"], b["bgr"])
+
+
+def test_degenerate_depth_zero_and_behind_camera(built):
+    """z == 0 takes the `z ? 1/z : 1` branch; points behind the camera are not culled."""
+    from voxcarve.camera import Camera
+    cam = Camera(np.array([[50, 0, 20], [0, 50, 20], [0, 0, 1.0]]), np.zeros(5), np.zeros(3), np.zeros(3))
+    pts = np.array([[1.0, 2.0, 0.0], [0.1, 0.1, -1.0], [0.0, 0.0, 5.0], [1e308, 1.0, 1e-308]])
+    uv = carve_np.project_points(pts, cam.R, cam.tvec, cam.K, cam.dist)
+    assert np.array_equal(uv[0], [70.0, 120.0])          # z = 0 -> scale 1
+    assert np.array_equal(uv[1], [15.0, 15.0])           # behind the camera still projects
+    assert np.array_equal(uv[2], [20.0, 20.0])
+    uvc = carve_c.project(pts, (cam.K, cam.dist, cam.R, cam.tvec))
+    off_np = carve_np.pixel_offsets(uv, 40, 40)
+    off_c = carve_np.pixel_offsets(uvc, 40, 40)
+    assert np.array_equal(off_np, off_c)                  # non-finite rows agree after the bounds test
+    assert np.array_equal(uv[:3], uvc[:3])
+
+
+def test_bounds_test_is_on_float_coordinates():
+    uv = np.array([[-0.5, 3.0], [3.0, -0.25], [0.0, 0.0], [9.999, 4.999], [10.0, 1.0], [np.nan, 1.0], [np.inf, 1]])
+    off = carve_np.pixel_offsets(uv, 5, 10)
+    assert off.tolist() == [-1, -1, 0, 49, -1, -1, -1]
+
+
+def test_index_range_slabs_concatenate(built, cams, masks, frames):
+    oc = fx.oracle_cams(cams)
+    full = carve_c.carve(32, 32, 32, oc, masks, frames)
+    parts = [carve_c.carve(32, 32, 32, oc, masks, frames, index_range=(z0 * 1024, z1 * 1024))
+             for z0, z1 in ((0, 10), (10, 11), (11, 32))]
+    assert np.array_equal(np.concatenate([p["idx"] for p in parts]), full["idx"])
+    assert np.array_equal(np.concatenate([p["bgr"] for p in parts]), full["bgr"])

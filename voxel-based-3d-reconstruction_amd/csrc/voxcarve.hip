@@ -1,0 +1,943 @@
+// libvoxcarve.so -- MI355X (gfx950) visual-hull carve engine: kernels + C ABI.
+//
+// Path replaced (reference root = ChristosP1/Voxel-Based-3D-Reconstruction):
+//   create_voxel_volume                        voxel_reconstruction.py:35-59
+//   create_lookup_table (cv2.projectPoints)    voxel_reconstruction.py:62-86
+//   update_visible_voxels_and_extract_colors   voxel_reconstruction.py:89-124
+//   selection loop of set_voxel_positions      assignment.py:116-133
+//
+// Data layout in HBM (per context = per rank = one z-slab of n voxels, slab-local j):
+//   axes      f64 xs[nx], ys[ny], zs[nz]        np.linspace tables (host-built, exact)
+//   maskbits  u32 [slot][C][ceil(H*W/32)]       bit b of word w = pixel 32w+b foreground
+//   frames    u8  [slot][C][H*W*3]              BGR, only the colour camera is read
+//   lut       i32 [C][n]                        pixel offset or -1 (VC_MODE_LUT)
+//   words     u64 [ceil(n/64)]                  survivor bit per voxel (= dense occupancy)
+//   tilecnt   u32 [ceil(words/256)]             survivors per 16384-voxel tile
+//   tileoff   u64 [tiles]                       exclusive scan of tilecnt
+//   records   u64 [S]                           {u32 idx, r, g, b, seen}, ascending idx
+//
+// There is no CPU path in this library: without a GPU vc_create fails (VC_ERR_NODEV).
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and enums only; the functions are resolved with dlsym
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/voxcarve.h"
+#include "vc_device.h"
+
+#pragma clang fp contract(off)
+
+using vc::CamDev;
+
+namespace {
+
+constexpr uint32_t kBlock = 256;            // 4 waves of 64
+constexpr uint32_t kWordsPerTile = 256;     // 16384 voxels per compaction tile
+
+struct CarveParams {
+    const double *xs, *ys, *zs;
+    const uint32_t *maskbits;   // [C][mwords] of the active slot
+    const int32_t *lut;         // [C][n]
+    uint64_t *words;
+    uint32_t *tilecnt;
+    uint16_t *viewmask;
+    uint64_t n;                 // voxels in the slab
+    uint32_t nx, ny, nz, z0;
+    uint32_t C, H, W, mwords;
+    uint32_t min_views;
+    CamDev cam[VC_MAX_CAMERAS];
+};
+
+struct EmitParams {
+    const double *xs, *ys, *zs;
+    const uint32_t *maskbits;   // colour camera's mask of the active slot (or null)
+    const uint8_t *frame;       // colour camera's BGR image (or null)
+    const uint64_t *words;
+    const uint32_t *tilecnt;
+    const uint64_t *tileoff;
+    uint64_t *records;
+    uint64_t capacity;
+    uint64_t n;
+    uint64_t i0;                // global linear index of slab-local voxel 0
+    uint32_t nx, ny, z0;
+    uint32_t H, W;
+    int has_cam;
+    CamDev cam;
+};
+
+__device__ __forceinline__ void decompose(uint64_t j, uint32_t nx, uint32_t ny,
+                                          uint32_t &ix, uint32_t &iy, uint32_t &izl)
+{
+    const uint64_t t = j / ny;
+    iy = (uint32_t)(j - t * ny);
+    izl = (uint32_t)(t / nx);
+    ix = (uint32_t)(t - (uint64_t)izl * nx);
+}
+
+// ---------------------------------------------------------------- mask bit-packing
+// One thread per output word: 32 mask bytes -> 32 bits (foreground where byte > 0,
+// voxel_reconstruction.py:112).
+__global__ __launch_bounds__(kBlock) void k_pack_masks(const uint8_t *__restrict__ bytes,
+                                                       uint32_t *__restrict__ bits,
+                                                       uint32_t C, uint32_t HW, uint32_t mwords)
+{
+    const uint32_t w = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t c = blockIdx.y;
+    if (w >= mwords || c >= C) return;
+    const uint8_t *src = bytes + (size_t)c * HW;
+    const uint32_t p0 = w * 32u;
+    uint32_t out = 0;
+    if (p0 + 32u <= HW && ((reinterpret_cast<uintptr_t>(src + p0) & 3u) == 0)) {
+        const uint32_t *s4 = reinterpret_cast<const uint32_t *>(src + p0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t v = s4[q];
+            out |= ((v & 0x000000ffu) ? 1u : 0u) << (4 * q + 0);
+            out |= ((v & 0x0000ff00u) ? 1u : 0u) << (4 * q + 1);
+            out |= ((v & 0x00ff0000u) ? 1u : 0u) << (4 * q + 2);
+            out |= ((v & 0xff000000u) ? 1u : 0u) << (4 * q + 3);
+        }
+    } else {
+        for (uint32_t b = 0; b < 32u && p0 + b < HW; ++b) out |= (src[p0 + b] ? 1u : 0u) << b;
+    }
+    bits[(size_t)c * mwords + w] = out;
+}
+
+// ---------------------------------------------------------------- generic carve
+// One thread per voxel, any grid shape.  LUT = stream the packed table instead of
+// projecting; VM = also store the per-voxel camera bitmask (no early exit then).
+template <bool LUT, bool VM>
+__global__ __launch_bounds__(kBlock) void k_carve_generic(const CarveParams p)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = j < p.n;
+    uint32_t vm = 0, cnt = 0;
+    if (valid) {
+        double X = 0, Y = 0, Z = 0;
+        if (!LUT) {
+            uint32_t ix, iy, izl;
+            decompose(j, p.nx, p.ny, ix, iy, izl);
+            X = p.xs[ix];
+            Y = p.ys[iy];
+            Z = p.zs[p.z0 + izl];
+        }
+        for (uint32_t c = 0; c < p.C; ++c) {
+            // Voxels that can no longer reach min_views stop early (result unchanged).
+            if (!VM && cnt + (p.C - c) < p.min_views) break;
+            int32_t off;
+            if (LUT) {
+                off = p.lut[(size_t)c * p.n + j];
+            } else {
+                double u, v;
+                vc::project_point(p.cam[c], X, Y, Z, u, v);
+                off = vc::pixel_offset(u, v, p.H, p.W);
+            }
+            if (off >= 0 && vc::mask_bit(p.maskbits + (size_t)c * p.mwords, off)) {
+                vm |= 1u << c;
+                ++cnt;
+            }
+        }
+        if (VM) p.viewmask[j] = (uint16_t)vm;
+    }
+    const bool keep = valid && cnt >= p.min_views;
+    const uint64_t ballot = __ballot(keep);
+    if ((threadIdx.x & 63u) == 0) {
+        const uint64_t w = j >> 6;
+        p.words[w] = ballot;
+        if (ballot) atomicAdd(&p.tilecnt[w / kWordsPerTile], (uint32_t)__popcll(ballot));
+    }
+}
+
+// ---------------------------------------------------------------- LUT build
+__global__ __launch_bounds__(kBlock) void k_build_lut(const CarveParams p, int32_t *__restrict__ lut)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= p.n) return;
+    uint32_t ix, iy, izl;
+    decompose(j, p.nx, p.ny, ix, iy, izl);
+    const double X = p.xs[ix], Y = p.ys[iy], Z = p.zs[p.z0 + izl];
+    for (uint32_t c = 0; c < p.C; ++c) {
+        double u, v;
+        vc::project_point(p.cam[c], X, Y, Z, u, v);
+        lut[(size_t)c * p.n + j] = vc::pixel_offset(u, v, p.H, p.W);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_project(const CamDev cam, const double *__restrict__ xyz,
+                                                    uint64_t n, double *__restrict__ uv)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    double u, v;
+    vc::project_point(cam, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], u, v);
+    uv[2 * i] = u;
+    uv[2 * i + 1] = v;
+}
+
+// ---------------------------------------------------------------- compaction
+// Exclusive scan of the per-tile survivor counts: one workgroup, sequential chunks.
+__global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t *__restrict__ cnt,
+                                                     uint64_t *__restrict__ off, uint64_t ntiles,
+                                                     uint64_t *__restrict__ total)
+{
+    __shared__ uint64_t part[1024];
+    const uint32_t t = threadIdx.x;
+    const uint64_t per = (ntiles + 1023) / 1024;
+    const uint64_t b = t * per;
+    const uint64_t e = (b + per < ntiles) ? b + per : ntiles;
+    uint64_t s = 0;
+    for (uint64_t i = b; i < e; ++i) s += cnt[i];
+    part[t] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {       // Hillis-Steele inclusive scan
+        uint64_t v = (t >= d) ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint64_t run = part[t] - s;
+    for (uint64_t i = b; i < e; ++i) {
+        off[i] = run;
+        run += cnt[i];
+    }
+    if (t == 1023) *total = part[1023];
+}
+
+// One workgroup per tile, one thread per 64-voxel word: ordered expansion of the
+// survivor bits into records, with the colour-camera sample (assignment.py:133).
+__global__ __launch_bounds__(kBlock) void k_emit(const EmitParams p)
+{
+    __shared__ uint32_t wsum[4];
+    const uint64_t tile = blockIdx.x;
+    if (p.tilecnt[tile] == 0) return;                 // uniform per workgroup
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint64_t w = tile * kWordsPerTile + t;
+    const uint64_t nwords = (p.n + 63) >> 6;
+    uint64_t bits = (w < nwords) ? p.words[w] : 0;
+    const uint32_t c = (uint32_t)__popcll(bits);
+    uint32_t incl = c;                                 // inclusive scan across the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d);
+        if (lane >= (uint32_t)d) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t k = 0; k < wave; ++k) base += wsum[k];
+    uint64_t pos = p.tileoff[tile] + base + (incl - c);
+    while (bits) {
+        const uint32_t b = (uint32_t)__builtin_ctzll(bits);
+        bits &= bits - 1;
+        const uint64_t j = (w << 6) + b;
+        uint64_t rec = (uint32_t)(p.i0 + j);
+        if (p.has_cam) {
+            uint32_t ix, iy, izl;
+            decompose(j, p.nx, p.ny, ix, iy, izl);
+            double u, v;
+            vc::project_point(p.cam, p.xs[ix], p.ys[iy], p.zs[p.z0 + izl], u, v);
+            const int32_t off = vc::pixel_offset(u, v, p.H, p.W);
+            if (off >= 0 && p.maskbits && vc::mask_bit(p.maskbits, off)) {
+                uint64_t r = 0, g = 0, bl = 0;
+                if (p.frame) {
+                    const uint8_t *px = p.frame + 3 * (size_t)off;
+                    bl = px[0]; g = px[1]; r = px[2];
+                }
+                rec |= (r << 32) | (g << 40) | (bl << 48) | (1ull << 56);
+            }
+        }
+        if (pos < p.capacity) p.records[pos] = rec;
+        ++pos;
+    }
+}
+
+// ================================================================ host side
+struct RcclApi {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+RcclApi g_rccl;
+std::string g_create_error;
+
+// RCCL is resolved at first use so single-GPU runs never load it, and so that a
+// process which already holds a librccl.so.1 (any host framework) shares that copy.
+bool load_rccl(std::string &err)
+{
+    if (g_rccl.handle) return true;
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { err = std::string("dlopen librccl: ") + dlerror(); return false; }
+#define VC_SYM(field, name)                                                             \
+    g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(h, name));            \
+    if (!g_rccl.field) { err = std::string("dlsym ") + name + " failed"; return false; }
+    VC_SYM(GetUniqueId, "ncclGetUniqueId")
+    VC_SYM(CommInitRank, "ncclCommInitRank")
+    VC_SYM(CommDestroy, "ncclCommDestroy")
+    VC_SYM(AllGather, "ncclAllGather")
+    VC_SYM(Broadcast, "ncclBroadcast")
+    VC_SYM(GroupStart, "ncclGroupStart")
+    VC_SYM(GroupEnd, "ncclGroupEnd")
+    VC_SYM(GetErrorString, "ncclGetErrorString")
+#undef VC_SYM
+    g_rccl.handle = h;
+    return true;
+}
+
+template <typename T>
+struct DevBuf {
+    T *ptr = nullptr;
+    size_t cap = 0;     // elements
+};
+
+struct Slot {
+    DevBuf<uint32_t> bits;      // [C][mwords]
+    DevBuf<uint8_t> frames;     // [C][H*W*3]
+    std::vector<uint8_t> have_frame;
+    bool have_masks = false;
+};
+
+// np.linspace(lo, hi, num=n) in float64: y[k] = k*step + lo (two roundings), y[n-1] = hi
+// (voxel_reconstruction.py:52-54).  Host code of this file is built contraction-free too.
+void linspace(double lo, double hi, uint32_t n, std::vector<double> &out)
+{
+    out.resize(n);
+    if (n == 0) return;
+    if (n == 1) { out[0] = lo; return; }
+    const double delta = hi - lo;
+    const double div = (double)(n - 1);
+    const double step = delta / div;
+    for (uint32_t k = 0; k < n; ++k) {
+        const double kk = (double)k;
+        const double y = (step == 0.0) ? (kk / div) * delta : kk * step;
+        out[k] = y + lo;
+    }
+    out[n - 1] = hi;
+}
+
+}  // namespace
+
+struct vc_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::string err;
+
+    // grid
+    uint32_t nx = 0, ny = 0, nz = 0, z0 = 0, z1 = 0;
+    double bounds[6] = {0, 0, 0, 0, 0, 0};
+    std::vector<double> xs, ys, zs;
+    DevBuf<double> d_axes;           // xs | ys | zs
+    bool have_grid = false;
+
+    // cameras
+    uint32_t C = 0, H = 0, W = 0, mwords = 0;
+    CamDev cams[VC_MAX_CAMERAS];
+    bool have_cams = false;
+
+    std::vector<Slot> slots;
+    DevBuf<uint8_t> d_stage;         // H2D staging for byte masks
+
+    DevBuf<int32_t> d_lut;
+    bool lut_valid = false;
+    DevBuf<uint64_t> d_words;
+    DevBuf<uint32_t> d_tilecnt;
+    DevBuf<uint64_t> d_tileoff;      // + 1 slot for the total
+    DevBuf<uint16_t> d_viewmask;
+    DevBuf<uint64_t> d_records;
+    DevBuf<double> d_scratch;
+    uint64_t *h_total = nullptr;     // pinned
+    bool viewmask_valid = false, carved = false;
+    uint64_t survivors = 0;
+
+    // comm
+    ncclComm_t comm = nullptr;
+    int n_ranks = 1, rank = 0;
+    DevBuf<uint64_t> d_counts, d_gathered;
+    uint64_t *h_counts = nullptr;    // pinned, n_ranks
+    uint64_t gathered_total = 0;
+    bool gathered = false;
+
+    vc_timing_t tm;
+
+    uint64_t n_voxels() const { return (uint64_t)nx * ny * (z1 - z0); }
+    uint64_t i0() const { return (uint64_t)z0 * nx * ny; }
+};
+
+namespace {
+
+int fail(vc_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define VC_HIP(ctx, call)                                                                      \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? VC_ERR_OOM : VC_ERR_HIP, "%s: %s",    \
+                        #call, hipGetErrorString(e_));                                         \
+    } while (0)
+
+#define VC_NCCL(ctx, call)                                                                     \
+    do {                                                                                       \
+        ncclResult_t r_ = (call);                                                              \
+        if (r_ != ncclSuccess)                                                                 \
+            return fail(ctx, VC_ERR_RCCL, "%s: %s", #call, g_rccl.GetErrorString(r_));         \
+    } while (0)
+
+template <typename T>
+int ensure(vc_ctx *ctx, DevBuf<T> &b, size_t elems)
+{
+    if (elems <= b.cap && b.ptr) return VC_OK;
+    if (b.ptr) { VC_HIP(ctx, hipFree(b.ptr)); b.ptr = nullptr; b.cap = 0; }
+    if (elems == 0) elems = 1;
+    VC_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&b.ptr), elems * sizeof(T)));
+    b.cap = elems;
+    return VC_OK;
+}
+
+template <typename T>
+void release(DevBuf<T> &b)
+{
+    if (b.ptr) (void)hipFree(b.ptr);
+    b.ptr = nullptr;
+    b.cap = 0;
+}
+
+#define VC_TRY(expr)              \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_ != VC_OK) return rc_; \
+    } while (0)
+
+void fill_params(const vc_ctx *ctx, CarveParams &p)
+{
+    memset(&p, 0, sizeof p);
+    p.xs = ctx->d_axes.ptr;
+    p.ys = p.xs + ctx->nx;
+    p.zs = p.ys + ctx->ny;
+    p.n = ctx->n_voxels();
+    p.nx = ctx->nx; p.ny = ctx->ny; p.nz = ctx->nz; p.z0 = ctx->z0;
+    p.C = ctx->C; p.H = ctx->H; p.W = ctx->W; p.mwords = ctx->mwords;
+    memcpy(p.cam, ctx->cams, sizeof(CamDev) * ctx->C);
+}
+
+int slot_at(vc_ctx *ctx, uint32_t slot, Slot **out)
+{
+    if (!ctx->have_cams) return fail(ctx, VC_ERR_ARG, "vc_set_cameras must precede frame uploads");
+    if (slot >= 64) return fail(ctx, VC_ERR_ARG, "slot %u out of range (max 64 resident frame sets)", slot);
+    if (slot >= ctx->slots.size()) ctx->slots.resize(slot + 1);
+    Slot &s = ctx->slots[slot];
+    if (s.have_frame.size() != ctx->C) s.have_frame.assign(ctx->C, 0);
+    *out = &s;
+    return VC_OK;
+}
+
+uint32_t grid_for(uint64_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
+
+}  // namespace
+
+// ================================================================ C ABI
+extern "C" {
+
+int vc_device_count(int *n_out)
+{
+    if (!n_out) return VC_ERR_ARG;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *n_out = 0; return fail(nullptr, VC_ERR_NODEV, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *n_out = n;
+    return VC_OK;
+}
+
+int vc_create(int device, vc_ctx **out)
+{
+    if (!out) return VC_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, VC_ERR_NODEV, "no HIP device (%s); voxcarve has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "count 0");
+    if (device < 0 || device >= n) return fail(nullptr, VC_ERR_ARG, "device %d not in [0,%d)", device, n);
+    hipDeviceProp_t prop;
+    VC_HIP(nullptr, hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, VC_ERR_NODEV, "device %d is %s; this library carries gfx950 code only",
+                    device, prop.gcnArchName);
+    VC_HIP(nullptr, hipSetDevice(device));
+    vc_ctx *ctx = new vc_ctx();
+    ctx->device = device;
+    memset(&ctx->tm, 0, sizeof ctx->tm);
+    hipError_t e1 = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    for (int i = 0; i < 4 && e1 == hipSuccess; ++i) e1 = hipEventCreate(&ctx->ev[i]);
+    if (e1 == hipSuccess) e1 = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_total), sizeof(uint64_t), hipHostMallocDefault);
+    if (e1 != hipSuccess) {
+        int rc = fail(nullptr, VC_ERR_HIP, "context setup: %s", hipGetErrorString(e1));
+        delete ctx;
+        return rc;
+    }
+    *out = ctx;
+    return VC_OK;
+}
+
+int vc_destroy(vc_ctx *ctx)
+{
+    if (!ctx) return VC_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
+    for (Slot &s : ctx->slots) { release(s.bits); release(s.frames); }
+    release(ctx->d_axes); release(ctx->d_stage); release(ctx->d_lut); release(ctx->d_words);
+    release(ctx->d_tilecnt); release(ctx->d_tileoff); release(ctx->d_viewmask);
+    release(ctx->d_records); release(ctx->d_scratch); release(ctx->d_counts); release(ctx->d_gathered);
+    if (ctx->h_total) (void)hipHostFree(ctx->h_total);
+    if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
+    for (int i = 0; i < 4; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return VC_OK;
+}
+
+const char *vc_last_error(const vc_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int vc_synchronize(vc_ctx *ctx)
+{
+    if (!ctx) return VC_ERR_ARG;
+    VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VC_OK;
+}
+
+int vc_set_grid(vc_ctx *ctx, uint32_t nx, uint32_t ny, uint32_t nz, const double bounds[6])
+{
+    if (!ctx || !bounds) return VC_ERR_ARG;
+    if (nx == 0 || ny == 0 || nz == 0) return fail(ctx, VC_ERR_ARG, "grid dimensions must be >= 1");
+    const uint64_t N = (uint64_t)nx * ny * nz;
+    if (N > 0xffffffffull || (uint64_t)nx * ny > 0xffffffffull)
+        return fail(ctx, VC_ERR_ARG, "grid of %llu voxels exceeds the u32 voxel index", (unsigned long long)N);
+    VC_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->nx = nx; ctx->ny = ny; ctx->nz = nz; ctx->z0 = 0; ctx->z1 = nz;
+    memcpy(ctx->bounds, bounds, sizeof ctx->bounds);
+    linspace(bounds[0], bounds[1], nx, ctx->xs);
+    linspace(bounds[2], bounds[3], ny, ctx->ys);
+    linspace(bounds[4], bounds[5], nz, ctx->zs);
+    VC_TRY(ensure(ctx, ctx->d_axes, (size_t)nx + ny + nz));
+    VC_HIP(ctx, hipMemcpyAsync(ctx->d_axes.ptr, ctx->xs.data(), sizeof(double) * nx, hipMemcpyHostToDevice, ctx->stream));
+    VC_HIP(ctx, hipMemcpyAsync(ctx->d_axes.ptr + nx, ctx->ys.data(), sizeof(double) * ny, hipMemcpyHostToDevice, ctx->stream));
+    VC_HIP(ctx, hipMemcpyAsync(ctx->d_axes.ptr + nx + ny, ctx->zs.data(), sizeof(double) * nz, hipMemcpyHostToDevice, ctx->stream));
+    VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_grid = true;
+    ctx->lut_valid = false; ctx->carved = false; ctx->gathered = false; ctx->viewmask_valid = false;
+    return VC_OK;
+}
+
+int vc_set_slab(vc_ctx *ctx, uint32_t z0, uint32_t z1)
+{
+    if (!ctx) return VC_ERR_ARG;
+    if (!ctx->have_grid) return fail(ctx, VC_ERR_ARG, "vc_set_grid must precede vc_set_slab");
+    if (z0 > z1 || z1 > ctx->nz) return fail(ctx, VC_ERR_ARG, "slab [%u,%u) outside [0,%u]", z0, z1, ctx->nz);
+    ctx->z0 = z0; ctx->z1 = z1;
+    ctx->lut_valid = false; ctx->carved = false; ctx->gathered = false; ctx->viewmask_valid = false;
+    return VC_OK;
+}
+
+int vc_get_axes(vc_ctx *ctx, double *xs, double *ys, double *zs)
+{
+    if (!ctx || !ctx->have_grid) return ctx ? fail(ctx, VC_ERR_ARG, "no grid") : VC_ERR_ARG;
+    VC_HIP(ctx, hipSetDevice(ctx->device));
+    if (xs) VC_HIP(ctx, hipMemcpy(xs, ctx->d_axes.ptr, sizeof(double) * ctx->nx, hipMemcpyDeviceToHost));
+    if (ys) VC_HIP(ctx, hipMemcpy(ys, ctx->d_axes.ptr + ctx->nx, sizeof(double) * ctx->ny, hipMemcpyDeviceToHost));
+    if (zs) VC_HIP(ctx, hipMemcpy(zs, ctx->d_axes.ptr + ctx->nx + ctx->ny, sizeof(double) * ctx->nz, hipMemcpyDeviceToHost));
+    return VC_OK;
+}
+
+int vc_set_cameras(vc_ctx *ctx, uint32_t C, const double *K9, const double *dist5, const double *R9,
+                   const double *t3, uint32_t H, uint32_t W)
+{
+    if (!ctx || !K9 || !dist5 || !R9 || !t3) return VC_ERR_ARG;
+    if (C == 0 || C > VC_MAX_CAMERAS) return fail(ctx, VC_ERR_ARG, "camera count %u not in [1,%d]", C, VC_MAX_CAMERAS);
+    if (H == 0 || W == 0 || (uint64_t)H * W > 0x7fffffffull) return fail(ctx, VC_ERR_ARG, "bad mask size %ux%u", H, W);
+    for (uint32_t c = 0; c < C; ++c) {
+        CamDev &d = ctx->cams[c];
+        memcpy(d.r, R9 + 9 * c, sizeof d.r);
+        memcpy(d.t, t3 + 3 * c, sizeof d.t);
+        d.fx = K9[9 * c + 0]; d.cx = K9[9 * c + 2];
+        d.fy = K9[9 * c + 4]; d.cy = K9[9 * c + 5];
+        d.k1 = dist5[5 * c + 0]; d.k2 = dist5[5 * c + 1];
+        d.p1 = dist5[5 * c + 2]; d.p2 = dist5[5 * c + 3];
+        d.k3 = dist5[5 * c + 4];
+    }
+    const bool reshaped = (C != ctx->C || H != ctx->H || W != ctx->W);
+    ctx->C = C; ctx->H = H; ctx->W = W;
+    ctx->mwords = (uint32_t)(((uint64_t)H * W + 31) / 32);
+    ctx->have_cams = true;
+    if (reshaped) {
+        (void)hipSetDevice(ctx->device);
+        for (Slot &s : ctx->slots) { release(s.bits); release(s.frames); s.have_masks = false; s.have_frame.clear(); }
+    }
+    ctx->lut_valid = false; ctx->carved = false; ctx->gathered = false; ctx->viewmask_valid = false;
+    return VC_OK;
+}
+
+int vc_upload_masks(vc_ctx *ctx, uint32_t slot, const uint8_t *masks)
+{
+    if (!ctx || !masks) return VC_ERR_ARG;
+    Slot *s = nullptr;
+    VC_TRY(slot_at(ctx, slot, &s));
+    VC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t HW = (size_t)ctx->H * ctx->W;
+    VC_TRY(ensure(ctx, ctx->d_stage, HW * ctx->C + 64));
+    VC_TRY(ensure(ctx, s->bits, (size_t)ctx->mwords * ctx->C));
+    VC_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    VC_HIP(ctx, hipMemcpyAsync(ctx->d_stage.ptr, masks, HW * ctx->C, hipMemcpyHostToDevice, ctx->stream));
+    dim3 grid((ctx->mwords + kBlock - 1) / kBlock, ctx->C);
+    hipLaunchKernelGGL(k_pack_masks, grid, dim3(kBlock), 0, ctx->stream, ctx->d_stage.ptr, s->bits.ptr,
+                       ctx->C, (uint32_t)HW, ctx->mwords);
+    VC_HIP(ctx, hipGetLastError());
+    VC_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.h2d_ms, ctx->ev[0], ctx->ev[1]));
+    s->have_masks = true;
+    return VC_OK;
+}
+
+int vc_upload_frame(vc_ctx *ctx, uint32_t slot, uint32_t cam, const uint8_t *bgr)
+{
+    if (!ctx || !bgr) return VC_ERR_ARG;
+    Slot *s = nullptr;
+    VC_TRY(slot_at(ctx, slot, &s));
+    if (cam >= ctx->C) return fail(ctx, VC_ERR_ARG, "camera %u not in [0,%u)", cam, ctx->C);
+    VC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)ctx->H * ctx->W * 3;
+    VC_TRY(ensure(ctx, s->frames, bytes * ctx->C));
+    VC_HIP(ctx, hipMemcpyAsync(s->frames.ptr + bytes * cam, bgr, bytes, hipMemcpyHostToDevice, ctx->stream));
+    VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    s->have_frame[cam] = 1;
+    return VC_OK;
+}
+
+int vc_build_lut(vc_ctx *ctx)
+{
+    if (!ctx) return VC_ERR_ARG;
+    if (!ctx->have_grid || !ctx->have_cams) return fail(ctx, VC_ERR_ARG, "grid and cameras must be set before vc_build_lut");
+    VC_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t n = ctx->n_voxels();
+    VC_TRY(ensure(ctx, ctx->d_lut, (size_t)n * ctx->C));
+    if (n) {
+        CarveParams p;
+        fill_params(ctx, p);
+        VC_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+        hipLaunchKernelGGL(k_build_lut, dim3(grid_for(n)), dim3(kBlock), 0, ctx->stream, p, ctx->d_lut.ptr);
+        VC_HIP(ctx, hipGetLastError());
+        VC_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+        VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.lut_ms, ctx->ev[0], ctx->ev[1]));
+    }
+    ctx->lut_valid = true;
+    return VC_OK;
+}
+
+int vc_fetch_lut(vc_ctx *ctx, uint32_t cam, int32_t *out)
+{
+    if (!ctx || !out) return VC_ERR_ARG;
+    if (!ctx->lut_valid) return fail(ctx, VC_ERR_ARG, "no lookup table: call vc_build_lut");
+    if (cam >= ctx->C) return fail(ctx, VC_ERR_ARG, "camera %u not in [0,%u)", cam, ctx->C);
+    VC_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t n = ctx->n_voxels();
+    if (n) VC_HIP(ctx, hipMemcpy(out, ctx->d_lut.ptr + (size_t)cam * n, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return VC_OK;
+}
+
+int vc_project(vc_ctx *ctx, uint32_t cam, const double *xyz, uint64_t n, double *uv)
+{
+    if (!ctx || !xyz || !uv) return VC_ERR_ARG;
+    if (!ctx->have_cams || cam >= ctx->C) return fail(ctx, VC_ERR_ARG, "camera %u not set", cam);
+    if (n == 0) return VC_OK;
+    VC_HIP(ctx, hipSetDevice(ctx->device));
+    VC_TRY(ensure(ctx, ctx->d_scratch, (size_t)n * 5));
+    double *d_xyz = ctx->d_scratch.ptr, *d_uv = d_xyz + 3 * n;
+    VC_HIP(ctx, hipMemcpyAsync(d_xyz, xyz, sizeof(double) * 3 * n, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_project, dim3(grid_for(n)), dim3(kBlock), 0, ctx->stream, ctx->cams[cam], d_xyz, n, d_uv);
+    VC_HIP(ctx, hipGetLastError());
+    VC_HIP(ctx, hipMemcpyAsync(uv, d_uv, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, ctx->stream));
+    VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VC_OK;
+}
+
+int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int mode, uint32_t flags,
+             uint64_t *n_out)
+{
+    if (!ctx || !n_out) return VC_ERR_ARG;
+    *n_out = 0;
+    if (!ctx->have_grid || !ctx->have_cams) return fail(ctx, VC_ERR_ARG, "grid and cameras must be set before vc_carve");
+    if (slot >= ctx->slots.size() || !ctx->slots[slot].have_masks)
+        return fail(ctx, VC_ERR_ARG, "no masks uploaded in slot %u", slot);
+    if (mode != VC_MODE_FUSED && mode != VC_MODE_LUT) return fail(ctx, VC_ERR_ARG, "unknown mode %d", mode);
+    if (mode == VC_MODE_LUT && !ctx->lut_valid) return fail(ctx, VC_ERR_ARG, "VC_MODE_LUT needs vc_build_lut first");
+    if (color_cam >= (int)ctx->C) return fail(ctx, VC_ERR_ARG, "colour camera %d not in [0,%u)", color_cam, ctx->C);
+    if (min_views < 1) min_views = 1;            // a voxel no camera sees never enters voxels_visible
+    VC_HIP(ctx, hipSetDevice(ctx->device));
+    Slot &s = ctx->slots[slot];
+    const uint64_t n = ctx->n_voxels();
+    const bool want_vm = (flags & VC_FLAG_VIEWMASK) != 0;
+    ctx->carved = false; ctx->gathered = false; ctx->viewmask_valid = false;
+    ctx->survivors = 0;
+    ctx->tm.voxels = n;
+    if (n == 0) { ctx->carved = true; ctx->tm.survivors = 0; return VC_OK; }
+
+    const uint64_t nwords = (n + 63) / 64;
+    const uint64_t ntiles = (nwords + kWordsPerTile - 1) / kWordsPerTile;
+    VC_TRY(ensure(ctx, ctx->d_words, ntiles * kWordsPerTile));
+    VC_TRY(ensure(ctx, ctx->d_tilecnt, ntiles));
+    VC_TRY(ensure(ctx, ctx->d_tileoff, ntiles + 1));
+    if (want_vm) VC_TRY(ensure(ctx, ctx->d_viewmask, n));
+    if (!ctx->d_records.ptr) VC_TRY(ensure(ctx, ctx->d_records, (size_t)(n / 16 + 1024)));
+
+    CarveParams p;
+    fill_params(ctx, p);
+    p.maskbits = s.bits.ptr;
+    p.lut = ctx->d_lut.ptr;
+    p.words = ctx->d_words.ptr;
+    p.tilecnt = ctx->d_tilecnt.ptr;
+    p.viewmask = ctx->d_viewmask.ptr;
+    p.min_views = min_views;
+
+    VC_HIP(ctx, hipMemsetAsync(ctx->d_tilecnt.ptr, 0, ntiles * sizeof(uint32_t), ctx->stream));
+    VC_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    const dim3 grid(grid_for(n)), block(kBlock);
+    if (mode == VC_MODE_LUT) {
+        if (want_vm) hipLaunchKernelGGL((k_carve_generic<true, true>), grid, block, 0, ctx->stream, p);
+        else hipLaunchKernelGGL((k_carve_generic<true, false>), grid, block, 0, ctx->stream, p);
+    } else {
+        if (want_vm) hipLaunchKernelGGL((k_carve_generic<false, true>), grid, block, 0, ctx->stream, p);
+        else hipLaunchKernelGGL((k_carve_generic<false, false>), grid, block, 0, ctx->stream, p);
+    }
+    VC_HIP(ctx, hipGetLastError());
+    VC_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+
+    uint64_t *d_total = ctx->d_tileoff.ptr + ntiles;
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_tilecnt.ptr,
+                       ctx->d_tileoff.ptr, ntiles, d_total);
+    VC_HIP(ctx, hipGetLastError());
+
+    EmitParams e;
+    memset(&e, 0, sizeof e);
+    e.xs = p.xs; e.ys = p.ys; e.zs = p.zs;
+    e.words = ctx->d_words.ptr; e.tilecnt = ctx->d_tilecnt.ptr; e.tileoff = ctx->d_tileoff.ptr;
+    e.n = n; e.i0 = ctx->i0(); e.nx = ctx->nx; e.ny = ctx->ny; e.z0 = ctx->z0; e.H = ctx->H; e.W = ctx->W;
+    if (color_cam >= 0) {
+        e.has_cam = 1;
+        e.cam = ctx->cams[color_cam];
+        e.maskbits = s.bits.ptr + (size_t)color_cam * ctx->mwords;
+        if (s.frames.ptr && s.have_frame[color_cam])
+            e.frame = s.frames.ptr + (size_t)color_cam * ctx->H * ctx->W * 3;
+    }
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        e.records = ctx->d_records.ptr;
+        e.capacity = ctx->d_records.cap;
+        hipLaunchKernelGGL(k_emit, dim3((uint32_t)ntiles), block, 0, ctx->stream, e);
+        VC_HIP(ctx, hipGetLastError());
+        VC_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+        VC_HIP(ctx, hipMemcpyAsync(ctx->h_total, d_total, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (*ctx->h_total <= ctx->d_records.cap) break;
+        if (attempt == 1) return fail(ctx, VC_ERR_HIP, "survivor buffer still too small after regrow");
+        VC_TRY(ensure(ctx, ctx->d_records, (size_t)(*ctx->h_total + *ctx->h_total / 8 + 1024)));
+    }
+    ctx->survivors = *ctx->h_total;
+    float ms = 0;
+    VC_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    ctx->tm.carve_ms = ms;
+    ctx->tm.carve_ms_sum += ms;
+    ctx->tm.carve_launches += 1;
+    VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.compact_ms, ctx->ev[1], ctx->ev[2]));
+    ctx->tm.survivors = ctx->survivors;
+    ctx->carved = true;
+    ctx->viewmask_valid = want_vm;
+    *n_out = ctx->survivors;
+    return VC_OK;
+}
+
+int vc_fetch_records(vc_ctx *ctx, uint64_t *records)
+{
+    if (!ctx || !records) return VC_ERR_ARG;
+    if (!ctx->carved) return fail(ctx, VC_ERR_ARG, "no carve result to fetch");
+    VC_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->survivors)
+        VC_HIP(ctx, hipMemcpy(records, ctx->d_records.ptr, ctx->survivors * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return VC_OK;
+}
+
+int vc_fetch(vc_ctx *ctx, uint32_t *idx, uint8_t *rgb, uint8_t *seen)
+{
+    if (!ctx) return VC_ERR_ARG;
+    if (!ctx->carved) return fail(ctx, VC_ERR_ARG, "no carve result to fetch");
+    const uint64_t S = ctx->survivors;
+    if (S == 0) return VC_OK;
+    std::vector<uint64_t> rec(S);
+    VC_TRY(vc_fetch_records(ctx, rec.data()));
+    for (uint64_t k = 0; k < S; ++k) {
+        const uint64_t r = rec[k];
+        if (idx) idx[k] = (uint32_t)r;
+        if (rgb) { rgb[3 * k] = (uint8_t)(r >> 32); rgb[3 * k + 1] = (uint8_t)(r >> 40); rgb[3 * k + 2] = (uint8_t)(r >> 48); }
+        if (seen) seen[k] = (uint8_t)((r >> 56) & 1);
+    }
+    return VC_OK;
+}
+
+int vc_fetch_viewmask(vc_ctx *ctx, uint16_t *viewmask)
+{
+    if (!ctx || !viewmask) return VC_ERR_ARG;
+    if (!ctx->carved || !ctx->viewmask_valid) return fail(ctx, VC_ERR_ARG, "last carve did not keep the view mask (VC_FLAG_VIEWMASK)");
+    VC_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t n = ctx->n_voxels();
+    if (n) VC_HIP(ctx, hipMemcpy(viewmask, ctx->d_viewmask.ptr, n * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    return VC_OK;
+}
+
+int vc_fetch_occupancy(vc_ctx *ctx, uint8_t *bits)
+{
+    if (!ctx || !bits) return VC_ERR_ARG;
+    if (!ctx->carved) return fail(ctx, VC_ERR_ARG, "no carve result to fetch");
+    VC_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t nwords = (ctx->n_voxels() + 63) / 64;
+    if (nwords) VC_HIP(ctx, hipMemcpy(bits, ctx->d_words.ptr, nwords * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return VC_OK;
+}
+
+int vc_timing(vc_ctx *ctx, vc_timing_t *out)
+{
+    if (!ctx || !out) return VC_ERR_ARG;
+    *out = ctx->tm;
+    return VC_OK;
+}
+
+int vc_timing_reset(vc_ctx *ctx)
+{
+    if (!ctx) return VC_ERR_ARG;
+    ctx->tm.carve_launches = 0;
+    ctx->tm.carve_ms_sum = 0;
+    return VC_OK;
+}
+
+// ---------------------------------------------------------------- multi-GPU
+int vc_comm_unique_id(uint8_t out[VC_UNIQUE_ID_BYTES])
+{
+    if (!out) return VC_ERR_ARG;
+    std::string err;
+    if (!load_rccl(err)) return fail(nullptr, VC_ERR_RCCL, "%s", err.c_str());
+    static_assert(sizeof(ncclUniqueId) == VC_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId id;
+    VC_NCCL(nullptr, g_rccl.GetUniqueId(&id));
+    memcpy(out, &id, sizeof id);
+    return VC_OK;
+}
+
+int vc_comm_init(vc_ctx *ctx, int n_ranks, int rank, const uint8_t uid[VC_UNIQUE_ID_BYTES])
+{
+    if (!ctx || !uid) return VC_ERR_ARG;
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(ctx, VC_ERR_ARG, "rank %d of %d", rank, n_ranks);
+    std::string err;
+    if (!load_rccl(err)) return fail(ctx, VC_ERR_RCCL, "%s", err.c_str());
+    VC_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->comm) { g_rccl.CommDestroy(ctx->comm); ctx->comm = nullptr; }
+    ncclUniqueId id;
+    memcpy(&id, uid, sizeof id);
+    VC_NCCL(ctx, g_rccl.CommInitRank(&ctx->comm, n_ranks, id, rank));
+    ctx->n_ranks = n_ranks;
+    ctx->rank = rank;
+    VC_TRY(ensure(ctx, ctx->d_counts, (size_t)n_ranks + 1));
+    if (ctx->h_counts) { (void)hipHostFree(ctx->h_counts); ctx->h_counts = nullptr; }
+    VC_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_counts), sizeof(uint64_t) * n_ranks, hipHostMallocDefault));
+    return VC_OK;
+}
+
+int vc_comm_destroy(vc_ctx *ctx)
+{
+    if (!ctx) return VC_ERR_ARG;
+    if (ctx->comm) {
+        (void)hipSetDevice(ctx->device);
+        VC_NCCL(ctx, g_rccl.CommDestroy(ctx->comm));
+        ctx->comm = nullptr;
+    }
+    ctx->n_ranks = 1; ctx->rank = 0;
+    return VC_OK;
+}
+
+// Variable-length all-gather in rank order: counts first (one u64 per rank), then one
+// grouped broadcast per root straight into its displacement of the gathered buffer.  On
+// xGMI every root's chunk leaves over its own links, so the grouped broadcasts overlap.
+int vc_allgather(vc_ctx *ctx, uint64_t *counts_out, uint64_t *total_out)
+{
+    if (!ctx || !total_out) return VC_ERR_ARG;
+    if (!ctx->comm) return fail(ctx, VC_ERR_ARG, "vc_comm_init must precede vc_allgather");
+    if (!ctx->carved) return fail(ctx, VC_ERR_ARG, "no carve result to gather");
+    VC_HIP(ctx, hipSetDevice(ctx->device));
+    const int G = ctx->n_ranks;
+    uint64_t *d_mine = ctx->d_counts.ptr + G;
+    *ctx->h_total = ctx->survivors;
+    VC_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    VC_HIP(ctx, hipMemcpyAsync(d_mine, ctx->h_total, sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    VC_NCCL(ctx, g_rccl.AllGather(d_mine, ctx->d_counts.ptr, 1, ncclUint64, ctx->comm, ctx->stream));
+    VC_HIP(ctx, hipMemcpyAsync(ctx->h_counts, ctx->d_counts.ptr, sizeof(uint64_t) * G, hipMemcpyDeviceToHost, ctx->stream));
+    VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t total = 0;
+    for (int r = 0; r < G; ++r) total += ctx->h_counts[r];
+    VC_TRY(ensure(ctx, ctx->d_gathered, (size_t)total));
+    if (!ctx->d_records.ptr) VC_TRY(ensure(ctx, ctx->d_records, 1024));
+    VC_NCCL(ctx, g_rccl.GroupStart());
+    uint64_t disp = 0;
+    for (int r = 0; r < G; ++r) {
+        const uint64_t cnt = ctx->h_counts[r];
+        if (cnt) {
+            ncclResult_t rc = g_rccl.Broadcast(ctx->d_records.ptr, ctx->d_gathered.ptr + disp, cnt, ncclUint64, r,
+                                               ctx->comm, ctx->stream);
+            if (rc != ncclSuccess) {
+                g_rccl.GroupEnd();
+                return fail(ctx, VC_ERR_RCCL, "ncclBroadcast(root %d): %s", r, g_rccl.GetErrorString(rc));
+            }
+        }
+        disp += cnt;
+    }
+    VC_NCCL(ctx, g_rccl.GroupEnd());
+    VC_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.gather_ms, ctx->ev[0], ctx->ev[1]));
+    if (counts_out) memcpy(counts_out, ctx->h_counts, sizeof(uint64_t) * G);
+    ctx->gathered_total = total;
+    ctx->gathered = true;
+    *total_out = total;
+    return VC_OK;
+}
+
+int vc_fetch_gathered(vc_ctx *ctx, uint64_t *records)
+{
+    if (!ctx || !records) return VC_ERR_ARG;
+    if (!ctx->gathered) return fail(ctx, VC_ERR_ARG, "no gathered result: call vc_allgather");
+    VC_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->gathered_total)
+        VC_HIP(ctx, hipMemcpy(records, ctx->d_gathered.ptr, ctx->gathered_total * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return VC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,236 @@
+"""CarveEngine: Python face of one libvoxcarve context (one GPU, one z-slab of the grid).
+
+Array-shaped fast path of the reference's carve step:
+voxel_reconstruction.py:35-124 + assignment.py:116-133.  All compute happens in the HIP
+library; this class only marshals numpy buffers across the C ABI.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .camera import Camera
+
+# reference voxel_reconstruction.py:35-36 (x_min, x_max, y_min, y_max, z_min, z_max)
+DEFAULT_BOUNDS = (-512.0, 1024.0, -1024.0, 1024.0, -2048.0, 512.0)
+SCALING_FACTOR = 64          # reference assignment.py:118
+COLOR_CAMERA_INDEX = 1       # reference assignment.py:133 uses camera key 2 (1-based)
+
+MODES = {"fused": _lib.VC_MODE_FUSED, "lut": _lib.VC_MODE_LUT}
+
+
+def _ptr(a, ctype):
+    return a.ctypes.data_as(ctypes.POINTER(ctype))
+
+
+class CarveEngine:
+    def __init__(self, device=0):
+        self._L = _lib.load()
+        self._ctx = _lib.c_ctx()
+        _lib.check(self._L.vc_create(int(device), ctypes.byref(self._ctx)), None, "vc_create")
+        self.device = device
+        self.grid = None
+        self.slab = None
+        self.n_cameras = 0
+        self.image_size = None
+        self.count = 0
+
+    # -- lifetime -----------------------------------------------------------------
+    def close(self):
+        if self._ctx:
+            self._L.vc_destroy(self._ctx)
+            self._ctx = _lib.c_ctx()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc, what):
+        _lib.check(rc, self._ctx, what)
+
+    # -- geometry -----------------------------------------------------------------
+    def set_grid(self, nx, ny, nz, bounds=DEFAULT_BOUNDS):
+        b = np.asarray(bounds, dtype=np.float64).reshape(6)
+        self._check(self._L.vc_set_grid(self._ctx, nx, ny, nz, _ptr(b, ctypes.c_double)), "vc_set_grid")
+        self.grid = (int(nx), int(ny), int(nz))
+        self.bounds = tuple(float(v) for v in b)
+        self.slab = (0, int(nz))
+
+    def set_slab(self, z0, z1):
+        self._check(self._L.vc_set_slab(self._ctx, z0, z1), "vc_set_slab")
+        self.slab = (int(z0), int(z1))
+
+    @property
+    def n_voxels(self):
+        nx, ny, _ = self.grid
+        return nx * ny * (self.slab[1] - self.slab[0])
+
+    @property
+    def index_base(self):
+        nx, ny, _ = self.grid
+        return self.slab[0] * nx * ny
+
+    def axes(self):
+        nx, ny, nz = self.grid
+        xs, ys, zs = np.empty(nx), np.empty(ny), np.empty(nz)
+        self._check(self._L.vc_get_axes(self._ctx, _ptr(xs, ctypes.c_double), _ptr(ys, ctypes.c_double),
+                                        _ptr(zs, ctypes.c_double)), "vc_get_axes")
+        return xs, ys, zs
+
+    # -- cameras ------------------------------------------------------------------
+    def set_cameras(self, cameras, H, W):
+        cams = [c if isinstance(c, Camera) else Camera(*c) for c in cameras]
+        K9 = np.ascontiguousarray([c.K.reshape(9) for c in cams], dtype=np.float64)
+        d5 = np.ascontiguousarray([c.dist for c in cams], dtype=np.float64)
+        R9 = np.ascontiguousarray([c.R.reshape(9) for c in cams], dtype=np.float64)
+        t3 = np.ascontiguousarray([c.tvec for c in cams], dtype=np.float64)
+        dp = ctypes.c_double
+        self._check(self._L.vc_set_cameras(self._ctx, len(cams), _ptr(K9, dp), _ptr(d5, dp), _ptr(R9, dp),
+                                           _ptr(t3, dp), H, W), "vc_set_cameras")
+        self.n_cameras = len(cams)
+        self.image_size = (int(H), int(W))
+
+    # -- per-frame inputs -----------------------------------------------------------
+    def upload_masks(self, masks, slot=0):
+        m = np.ascontiguousarray(np.stack([np.asarray(x) for x in masks]), dtype=np.uint8)
+        if m.shape != (self.n_cameras,) + self.image_size:
+            raise ValueError("masks shape %s, expected %s" % (m.shape, (self.n_cameras,) + self.image_size))
+        self._check(self._L.vc_upload_masks(self._ctx, slot, _ptr(m, ctypes.c_uint8)), "vc_upload_masks")
+
+    def upload_frame(self, cam, bgr, slot=0):
+        f = np.ascontiguousarray(bgr, dtype=np.uint8)
+        if f.shape != self.image_size + (3,):
+            raise ValueError("frame shape %s, expected %s" % (f.shape, self.image_size + (3,)))
+        self._check(self._L.vc_upload_frame(self._ctx, slot, cam, _ptr(f, ctypes.c_uint8)), "vc_upload_frame")
+
+    # -- lookup table ---------------------------------------------------------------
+    def build_lut(self):
+        self._check(self._L.vc_build_lut(self._ctx), "vc_build_lut")
+
+    def fetch_lut(self, cam):
+        out = np.empty(self.n_voxels, dtype=np.int32)
+        self._check(self._L.vc_fetch_lut(self._ctx, cam, _ptr(out, ctypes.c_int32)), "vc_fetch_lut")
+        return out
+
+    def project(self, cam, points):
+        p = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        uv = np.empty((p.shape[0], 2), dtype=np.float64)
+        self._check(self._L.vc_project(self._ctx, cam, _ptr(p, ctypes.c_double), p.shape[0],
+                                       _ptr(uv, ctypes.c_double)), "vc_project")
+        return uv
+
+    # -- hot path -------------------------------------------------------------------
+    def carve(self, slot=0, min_views=None, color_cam=COLOR_CAMERA_INDEX, mode="fused", viewmask=False):
+        """Runs the carve; returns the survivor count (records stay on the device)."""
+        n = ctypes.c_uint64(0)
+        mv = self.n_cameras if min_views is None else int(min_views)
+        cc = -1 if color_cam is None else int(color_cam)
+        flags = _lib.VC_FLAG_VIEWMASK if viewmask else 0
+        self._check(self._L.vc_carve(self._ctx, slot, mv, cc, MODES[mode], flags, ctypes.byref(n)), "vc_carve")
+        self.count = int(n.value)
+        return self.count
+
+    def fetch(self):
+        """(idx u32 [S] ascending global linear index, rgb u8 [S,3], seen bool [S])."""
+        S = self.count
+        idx = np.empty(S, dtype=np.uint32)
+        rgb = np.empty((S, 3), dtype=np.uint8)
+        seen = np.empty(S, dtype=np.uint8)
+        self._check(self._L.vc_fetch(self._ctx, _ptr(idx, ctypes.c_uint32), _ptr(rgb, ctypes.c_uint8),
+                                     _ptr(seen, ctypes.c_uint8)), "vc_fetch")
+        return idx, rgb, seen.astype(bool)
+
+    def fetch_records(self):
+        rec = np.empty(self.count, dtype=np.uint64)
+        self._check(self._L.vc_fetch_records(self._ctx, _ptr(rec, ctypes.c_uint64)), "vc_fetch_records")
+        return rec
+
+    def fetch_viewmask(self):
+        vm = np.empty(self.n_voxels, dtype=np.uint16)
+        self._check(self._L.vc_fetch_viewmask(self._ctx, _ptr(vm, ctypes.c_uint16)), "vc_fetch_viewmask")
+        return vm
+
+    def fetch_occupancy(self):
+        """Dense survivor bits of the slab: bool [n] (slab-local voxel order)."""
+        n = self.n_voxels
+        raw = np.empty(((n + 63) // 64) * 8, dtype=np.uint8)
+        self._check(self._L.vc_fetch_occupancy(self._ctx, _ptr(raw, ctypes.c_uint8)), "vc_fetch_occupancy")
+        return np.unpackbits(raw, bitorder="little")[:n].astype(bool)
+
+    def synchronize(self):
+        self._check(self._L.vc_synchronize(self._ctx), "vc_synchronize")
+
+    def timing(self, reset=False):
+        t = _lib.VcTiming()
+        self._check(self._L.vc_timing(self._ctx, ctypes.byref(t)), "vc_timing")
+        if reset:
+            self._check(self._L.vc_timing_reset(self._ctx), "vc_timing_reset")
+        return {name: getattr(t, name) for name, _ in _lib.VcTiming._fields_}
+
+    # -- multi-GPU -------------------------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        L = _lib.load()
+        buf = (ctypes.c_uint8 * _lib.VC_UNIQUE_ID_BYTES)()
+        _lib.check(L.vc_comm_unique_id(buf), None, "vc_comm_unique_id")
+        return bytes(buf)
+
+    def comm_init(self, n_ranks, rank, uid):
+        buf = (ctypes.c_uint8 * _lib.VC_UNIQUE_ID_BYTES).from_buffer_copy(uid)
+        self._check(self._L.vc_comm_init(self._ctx, n_ranks, rank, buf), "vc_comm_init")
+        self.n_ranks, self.rank = n_ranks, rank
+
+    def comm_destroy(self):
+        self._check(self._L.vc_comm_destroy(self._ctx), "vc_comm_destroy")
+
+    def allgather(self):
+        """RCCL all-gather of all ranks' survivor records; returns (counts per rank, total)."""
+        counts = np.zeros(getattr(self, "n_ranks", 1), dtype=np.uint64)
+        total = ctypes.c_uint64(0)
+        self._check(self._L.vc_allgather(self._ctx, _ptr(counts, ctypes.c_uint64), ctypes.byref(total)),
+                    "vc_allgather")
+        self.gathered_total = int(total.value)
+        return counts, self.gathered_total
+
+    def fetch_gathered(self):
+        rec = np.empty(self.gathered_total, dtype=np.uint64)
+        self._check(self._L.vc_fetch_gathered(self._ctx, _ptr(rec, ctypes.c_uint64)), "vc_fetch_gathered")
+        return rec
+
+
+# -- record / viewer helpers (host arithmetic of assignment.py:127-133) ----------------
+def unpack_records(rec):
+    """u64 records -> (idx u32, rgb u8 [S,3], seen bool)."""
+    rec = np.ascontiguousarray(rec, dtype=np.uint64)
+    b = rec.view(np.uint8).reshape(-1, 8)
+    return rec.astype(np.uint32), b[:, 4:7].copy(), (b[:, 7] & 1).astype(bool)
+
+
+def voxel_keys(idx, grid, axes):
+    """tuple(map(int, voxel)) of voxel_reconstruction.py:84: truncated coordinates int64 [S,3]."""
+    nx, ny, _ = grid
+    xs, ys, zs = axes
+    idx = np.asarray(idx, dtype=np.int64)
+    iy = idx % ny
+    t = idx // ny
+    return np.stack([np.trunc(xs[t % nx]), np.trunc(ys[iy]), np.trunc(zs[t // nx])], axis=1).astype(np.int64)
+
+
+def viewer_positions(keys, scaling_factor=SCALING_FACTOR):
+    """assignment.py:127-130: x = vx/64, y = -(vz/64), z = vy/64 -> float32 [S,3] (as mesh.py:82 casts)."""
+    k = np.asarray(keys, dtype=np.int64)
+    pos = np.stack([k[:, 0] / scaling_factor, -(k[:, 2] / scaling_factor), k[:, 1] / scaling_factor], axis=1)
+    return pos.astype(np.float32)
+
+
+def viewer_colors(rgb):
+    """assignment.py:133: BGR[::-1] / 255.0 -> float32 [S,3] (as mesh.py:88 casts)."""
+    return (np.asarray(rgb, dtype=np.uint8) / 255.0).astype(np.float32)

@@ -1,0 +1,92 @@
+"""Multi-GPU carve: block-split of the grid along z and the survivor all-gather.
+
+Every voxel is independent (reference voxel_reconstruction.py:105-122 loops over them),
+so the grid shards with no exchange until the end: rank r of G owns the z-slab
+iz in [floor(r*nz/G), floor((r+1)*nz/G)), a contiguous range of the linear voxel index
+(i = iz*nx*ny + ...), and the rank-ordered concatenation of the per-rank ascending survivor
+lists IS the reference's output order (assignment.py:121-133).  One process per GPU; the
+one collective is a variable-length all-gather of 8-byte survivor records, done by RCCL
+over xGMI inside libvoxcarve (vc_allgather).  The reference has no distributed code.
+
+A ``Transport`` moves the records between ranks:
+  RcclTransport   device-to-device via the engine's RCCL communicator (the product path)
+  TorchTransport  host tensors via a torch.distributed process group (gloo) -- exercises the
+                  same split / merge logic on CPU-only machines (tests)
+"""
+import numpy as np
+
+
+def slab_range(nz, n_ranks, rank):
+    """z-range [z0, z1) of rank r: floor split, empty slabs allowed when n_ranks > nz."""
+    if not (0 <= rank < n_ranks):
+        raise ValueError("rank %d not in [0,%d)" % (rank, n_ranks))
+    return (rank * nz) // n_ranks, ((rank + 1) * nz) // n_ranks
+
+
+def slab_index_range(grid, n_ranks, rank):
+    """Linear-index range [i0, i1) of rank r's slab."""
+    nx, ny, nz = grid
+    z0, z1 = slab_range(nz, n_ranks, rank)
+    return z0 * nx * ny, z1 * nx * ny
+
+
+def merge_rank_lists(per_rank_records):
+    """Concatenate per-rank record arrays in rank order and verify global ascending order."""
+    parts = [np.ascontiguousarray(p, dtype=np.uint64) for p in per_rank_records]
+    out = np.concatenate(parts) if parts else np.empty(0, np.uint64)
+    idx = out.astype(np.uint32)
+    if idx.size > 1 and not np.all(idx[1:] > idx[:-1]):
+        raise RuntimeError("gathered survivor list is not strictly ascending: slabs overlap or are misordered")
+    return out
+
+
+class RcclTransport:
+    """All-gather on the device through the engine's communicator (vc_comm_init / vc_allgather)."""
+
+    def __init__(self, engine, n_ranks, rank, uid):
+        self.engine = engine
+        engine.comm_init(n_ranks, rank, uid)
+
+    def allgather_records(self, local_records_unused=None):
+        counts, total = self.engine.allgather()
+        return counts, total
+
+    def fetch(self):
+        return self.engine.fetch_gathered()
+
+
+class TorchTransport:
+    """Variable-length all-gather of host records over a torch.distributed group (gloo)."""
+
+    def __init__(self, group=None):
+        import torch
+        import torch.distributed as dist
+        self._torch, self._dist, self._group = torch, dist, group
+        self._gathered = None
+
+    def allgather_records(self, local_records):
+        torch, dist = self._torch, self._dist
+        world = dist.get_world_size(self._group)
+        local = np.ascontiguousarray(local_records, dtype=np.uint64)
+        counts_t = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(counts_t, torch.tensor([local.size], dtype=torch.int64), group=self._group)
+        counts = np.array([int(t.item()) for t in counts_t], dtype=np.uint64)
+        cap = int(counts.max()) if counts.size else 0
+        send = torch.zeros(max(cap, 1), dtype=torch.int64)
+        send[:local.size] = torch.from_numpy(local.view(np.int64).copy())
+        recv = [torch.zeros(max(cap, 1), dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(recv, send, group=self._group)
+        parts = [recv[r][:int(counts[r])].numpy().view(np.uint64) for r in range(world)]
+        self._gathered = merge_rank_lists(parts)
+        return counts, int(counts.sum())
+
+    def fetch(self):
+        return self._gathered
+
+
+def carve_slab(engine, grid, n_ranks, rank, **carve_kwargs):
+    """Restrict ``engine`` to rank's slab and carve it; returns the local survivor count."""
+    z0, z1 = slab_range(grid[2], n_ranks, rank)
+    if engine.slab != (z0, z1):
+        engine.set_slab(z0, z1)
+    return engine.carve(**carve_kwargs)
