@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""bench.py -- visual-hull carve throughput on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path (reference voxel_reconstruction.py:89-124 +
+assignment.py:116-133) over one resident frame set: carve kernel -> tile scan -> ordered
+survivor records (+ RCCL all-gather of the records when N > 1).  Masks, frames, cameras
+and (LUT mode) the packed lookup table are resident in HBM before the timed region.
+
+Workload (config.workload): BASELINE configs[2]/[3] -- 1024^3 grid x 4 cameras, block-split
+along z over the N ranks (STRONG scaling: the grid is fixed, as BASELINE's ">= 6x at 8 GPUs"
+is stated).  Inputs: the reference's 4 calibrated cameras and frame-0 MOG masks (committed
+fixtures), the masks rolled by a few columns per step so no two consecutive steps see the
+same input; synthetic colour frames.
+
+  python bench.py [--gpus N --steps K --warmup W] [--grid 1024] [--mode lut|fused]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  `value` is the headline mode (default lut: the table-
+streaming form the reference's per-call function has, HBM-bound); the other mode is timed
+too and reported under "other_mode".  torch is imported only for the N > 1 rendezvous
+(gloo barrier / max-reduce); the data path is libvoxcarve + RCCL.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+F64_VALU_PEAK_TFLOPS = 78.6    # half the 157.3 TF fp32 vector figure; no MFMA on this path
+FLOP_PER_VV = 52               # f64 flop per voxel-view of the fused form (+1 divide)
+LUT_BYTES_PER_VV = 4           # one packed int32 per voxel-view
+N_SLOTS = 4
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--grid", type=int, default=1024)
+    ap.add_argument("--mode", choices=("lut", "fused"), default="lut")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+class Group:
+    """Rank bookkeeping; torch.distributed (gloo) only when world > 1."""
+
+    def __init__(self, n_gpus):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != n_gpus:
+            if self.world == 1 and n_gpus > 1:
+                raise SystemExit("--gpus %d needs one process per GPU: launch with "
+                                 "python -m torch.distributed.run --nproc-per-node %d bench.py ..." % (n_gpus, n_gpus))
+            raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (self.world, n_gpus))
+        self.dist = None
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            import torch.distributed as dist
+            dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            self.dist = dist
+
+    def barrier(self):
+        if self.dist:
+            self.dist.barrier()
+
+    def bcast_bytes(self, payload):
+        if not self.dist:
+            return payload
+        box = [payload]
+        self.dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    def max(self, x):
+        if not self.dist:
+            return x
+        import torch
+        t = torch.tensor([x], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum(self, x):
+        if not self.dist:
+            return x
+        import torch
+        t = torch.tensor([x], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def close(self):
+        if self.dist:
+            self.dist.destroy_process_group()
+
+
+def run_mode(eng, grp, mode, steps, warmup, multi):
+    """W untimed + K timed steps of one mode; returns (seconds, kernel ms avg, survivors, total)."""
+    def step(i):
+        n = eng.carve(slot=i % N_SLOTS, mode=mode)
+        if multi:
+            _, total = eng.allgather()
+            return n, total
+        return n, n
+
+    for i in range(warmup):
+        step(i)
+    eng.synchronize()
+    grp.barrier()
+    eng.timing(reset=True)
+    t0 = time.perf_counter()
+    last = (0, 0)
+    for i in range(steps):
+        last = step(warmup + i)
+    eng.synchronize()
+    grp.barrier()
+    dt = grp.max(time.perf_counter() - t0)
+    tm = eng.timing()
+    kernel_ms = tm["carve_ms_sum"] / max(1, tm["carve_launches"])
+    return dt, kernel_ms, last[0], last[1], tm
+
+
+def cpu_baseline(grid, cams, masks, frames, seconds):
+    """The C/OpenMP oracle ("port") on this host's cores, on a z-slab sample of the same grid."""
+    import fixtures_util as fx
+    from oracle import carve_c
+    oc = fx.oracle_cams(cams)
+    threads = len(os.sched_getaffinity(0))
+    layer = grid * grid
+    carve_c.carve(grid, grid, grid, oc, masks, frames, index_range=(0, layer * 2), threads=threads, cap=1 << 22)
+    probe = max(1, min(grid, 8))
+    z_mid = grid // 2
+    t0 = time.perf_counter()
+    carve_c.carve(grid, grid, grid, oc, masks, frames, index_range=(z_mid * layer, (z_mid + probe) * layer),
+                  threads=threads, cap=1 << 22)
+    per_layer = (time.perf_counter() - t0) / probe
+    layers = int(max(1, min(grid, seconds / max(per_layer, 1e-9))))
+    z0 = max(0, (grid - layers) // 2)
+    t0 = time.perf_counter()
+    res = carve_c.carve(grid, grid, grid, oc, masks, frames, index_range=(z0 * layer, (z0 + layers) * layer),
+                        threads=threads, cap=1 << 26)
+    dt = time.perf_counter() - t0
+    vv = layers * layer * len(cams)
+    return {"value": round(vv / dt / 1e6, 2), "unit": "Mvoxel-views/s", "cores": threads, "kind": "port",
+            "sample": "oracle/carve_ref.c (C/OpenMP, -O2 -ffp-contract=off), z-layers [%d,%d) of the %d^3 grid, "
+                      "%.3g voxel-views in %.2f s, %d survivors" % (z0, z0 + layers, grid, vv, dt, res["count"])}
+
+
+def main():
+    args = parse()
+    import voxcarve
+    voxcarve._lib.load()                 # libvoxcarve (system HIP runtime) is loaded before any torch import
+    grp = Group(args.gpus)
+    import fixtures_util as fx
+    from voxcarve import slabs
+
+    cams, masks = fx.golden_cameras(), fx.golden_masks()
+    H, W = masks[0].shape
+    C = len(cams)
+    frames = fx.synthetic_frames(C, H, W)
+    G = args.grid
+    grid = (G, G, G)
+
+    eng = voxcarve.CarveEngine(grp.local_rank)
+    eng.set_grid(*grid)
+    z0, z1 = slabs.slab_range(G, grp.world, grp.rank)
+    eng.set_slab(z0, z1)
+    eng.set_cameras(cams, H, W)
+    for s in range(N_SLOTS):
+        eng.upload_masks([np.roll(m, 3 * s, axis=1) for m in masks], slot=s)
+        eng.upload_frame(1, np.roll(frames[1], 3 * s, axis=1), slot=s)
+    multi = grp.world > 1
+    if multi:
+        uid = grp.bcast_bytes(voxcarve.CarveEngine.comm_unique_id() if grp.rank == 0 else None)
+        eng.comm_init(grp.world, grp.rank, uid)
+    eng.build_lut()
+    lut_ms = eng.timing()["lut_ms"]
+
+    results = {}
+    order = [args.mode] + [m for m in ("lut", "fused") if m != args.mode]
+    for mode in order:
+        dt, kernel_ms, n_local, n_total, tm = run_mode(eng, grp, mode, args.steps, args.warmup, multi)
+        results[mode] = {"seconds": dt, "kernel_ms": kernel_ms, "survivors": int(n_total),
+                         "compact_ms": tm["compact_ms"], "gather_ms": tm["gather_ms"]}
+
+    n_local_vox = eng.n_voxels
+    total_vv = float(G) ** 3 * C
+    head = results[args.mode]
+    ms_per_step = head["seconds"] / args.steps * 1e3
+    value = total_vv * args.steps / head["seconds"] / 1e6
+
+    # roofline of the dominant kernel of the headline mode, on THIS rank's launch
+    vv_launch = float(n_local_vox) * C
+    if args.mode == "lut":
+        alg_bytes = LUT_BYTES_PER_VV * vv_launch + 8.0 * head["survivors"] / grp.world + C * H * W / 8.0
+        achieved = alg_bytes / (head["kernel_ms"] * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "carve (LUT stream)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(head["kernel_ms"], 4)}
+    else:
+        achieved = FLOP_PER_VV * vv_launch / (head["kernel_ms"] * 1e-3) / 1e12
+        roof = {"bound": "valu_f64", "kernel": "carve (fused projection)", "achieved": round(achieved, 3),
+                "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F64_VALU_PEAK_TFLOPS, 4),
+                "traffic": None, "kernel_ms": round(head["kernel_ms"], 4)}
+    traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(traffic_file):
+        t = json.load(open(traffic_file)).get("%s_%d_g%d" % (args.mode, G, grp.world))
+        if t:
+            roof["traffic"] = t
+
+    other = [m for m in results if m != args.mode][0]
+    o = results[other]
+    out = {
+        "metric": "Mvoxel-views/s (grid N^3 x 4 cams)", "value": round(value, 1), "unit": "Mvoxel-views/s",
+        "n_gpus": grp.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "i32" if args.mode == "lut" else "f64",
+        "data": "reference calibration (4x config.xml) + frame-0 MOG mask fixtures rolled per step; synthetic colour frames",
+        "config": {"workload": "%d^3 voxel grid x %d cams (%dx%d masks), z-slab split over %d GPU(s), mode=%s, "
+                               "ordered survivor list + colour%s" % (G, C, W, H, grp.world, args.mode,
+                                                                     " + RCCL all-gather" if multi else ""),
+                   "grid": [G, G, G], "cameras": C, "mode": args.mode, "survivors": head["survivors"]},
+        "roofline": roof,
+        "other_mode": {"mode": other, "value": round(total_vv * args.steps / o["seconds"] / 1e6, 1),
+                       "ms_per_step": round(o["seconds"] / args.steps * 1e3, 4), "kernel_ms": round(o["kernel_ms"], 4),
+                       "survivors": o["survivors"]},
+        "phases_ms": {"carve_kernel": round(head["kernel_ms"], 4), "compact": round(head["compact_ms"], 4),
+                      "gather": round(head["gather_ms"], 4), "lut_build_once": round(lut_ms, 3)},
+    }
+    if grp.rank == 0 and grp.world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(G, cams, masks, frames, args.cpu_seconds)
+    elif grp.rank == 0:
+        out["cpu_baseline"] = None
+    eng.close()
+    grp.close()
+    if grp.rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
