@@ -1,0 +1,412 @@
+// gfx950 kernels of the carve path.  Host code and the C ABI: voxcarve.hip.
+//
+// Work decomposition: the slab's n voxels are numbered j = 0..n-1 in the reference's
+// order (y fastest, voxel_reconstruction.py:57).  A wavefront owns a CHUNK of KSUB x 64
+// consecutive voxels; sub-chunk k is one 64-voxel "word" whose survivor bits come out of a
+// single __ballot.  Cameras are visited most-selective first (order[]) and a sub-chunk
+// stops loading / projecting as soon as none of its 64 voxels can still pass.
+#pragma once
+#include "vc_device.h"
+
+#pragma clang fp contract(off)
+
+namespace vc {
+
+constexpr uint32_t kBlock = 256;            // 4 wavefronts
+constexpr uint32_t kWordsPerTile = 256;     // compaction tile = 16384 voxels
+constexpr uint32_t kScanBlock = 1024;       // tiles per scan workgroup
+constexpr uint32_t kMaxCameras = 16;
+
+struct CarveParams {
+    const double *xs, *ys, *zs;
+    const uint32_t *maskbits;   // [C][mwords] of the active frame set
+    const int32_t *lut;         // [C][n]
+    uint64_t *words;
+    uint32_t *tilecnt;
+    uint16_t *viewmask;
+    uint64_t n;                 // voxels in the slab (< 2^32)
+    uint32_t nx, ny, nz, z0;
+    uint32_t C, H, W, mwords;
+    uint32_t min_views;
+    uint32_t order[kMaxCameras];   // camera visiting order (most selective first)
+    CamDev cam[kMaxCameras];
+};
+
+struct EmitParams {
+    const double *xs, *ys, *zs;
+    const uint32_t *maskbits;   // colour camera's mask bits (or null)
+    const uint8_t *frame;       // colour camera's BGR image (or null)
+    const uint64_t *words;
+    const uint32_t *tilecnt;
+    const uint64_t *tileoff;    // exclusive scan inside each scan block
+    const uint64_t *blocksum;   // survivors per scan block
+    uint64_t *records;
+    uint64_t capacity;
+    uint64_t n;
+    uint64_t i0;                // global linear index of slab-local voxel 0
+    uint32_t nx, ny, z0;
+    uint32_t H, W;
+    int has_cam;
+    CamDev cam;
+};
+
+__device__ __forceinline__ void decompose(uint32_t j, uint32_t nx, uint32_t ny,
+                                          uint32_t &ix, uint32_t &iy, uint32_t &izl)
+{
+    const uint32_t t = j / ny;
+    iy = j - t * ny;
+    izl = t / nx;
+    ix = t - izl * nx;
+}
+
+// ---------------------------------------------------------------- mask bit-packing
+// One thread per output word: 32 mask bytes -> 32 bits (foreground where byte > 0,
+// voxel_reconstruction.py:112).
+__global__ __launch_bounds__(kBlock) void k_pack_masks(const uint8_t *__restrict__ bytes,
+                                                       uint32_t *__restrict__ bits,
+                                                       uint32_t C, uint32_t HW, uint32_t mwords)
+{
+    const uint32_t w = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t c = blockIdx.y;
+    if (w >= mwords || c >= C) return;
+    const uint8_t *src = bytes + (size_t)c * HW;
+    const uint32_t p0 = w * 32u;
+    uint32_t out = 0;
+    if (p0 + 32u <= HW && ((reinterpret_cast<uintptr_t>(src + p0) & 3u) == 0)) {
+        const uint32_t *s4 = reinterpret_cast<const uint32_t *>(src + p0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t v = s4[q];
+            out |= ((v & 0x000000ffu) ? 1u : 0u) << (4 * q + 0);
+            out |= ((v & 0x0000ff00u) ? 1u : 0u) << (4 * q + 1);
+            out |= ((v & 0x00ff0000u) ? 1u : 0u) << (4 * q + 2);
+            out |= ((v & 0xff000000u) ? 1u : 0u) << (4 * q + 3);
+        }
+    } else {
+        for (uint32_t b = 0; b < 32u && p0 + b < HW; ++b) out |= (src[p0 + b] ? 1u : 0u) << b;
+    }
+    bits[(size_t)c * mwords + w] = out;
+}
+
+// ---------------------------------------------------------------- camera selectivity
+// Pass count of each camera on `nsamples` evenly spaced voxels of the slab: the host
+// sorts cameras by it so the carve visits the most selective camera first.  Changes
+// the work done, never the result (the all-views test is a conjunction).
+__global__ __launch_bounds__(kBlock) void k_estimate(const CarveParams p, uint32_t *__restrict__ counts,
+                                                     uint32_t nsamples)
+{
+    const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = s < nsamples;
+    uint32_t ix = 0, iy = 0, izl = 0;
+    if (valid) decompose((uint32_t)(((uint64_t)s * p.n) / nsamples), p.nx, p.ny, ix, iy, izl);
+    const double X = p.xs[ix], Y = p.ys[iy], Z = p.zs[p.z0 + izl];
+    for (uint32_t c = 0; c < p.C; ++c) {
+        double u, v;
+        project_point(p.cam[c], X, Y, Z, u, v);
+        const int32_t off = pixel_offset(u, v, p.H, p.W);
+        const bool hit = valid && off >= 0 && mask_bit(p.maskbits + (size_t)c * p.mwords, off);
+        const uint64_t b = __ballot(hit);
+        if ((threadIdx.x & 63u) == 0 && b) atomicAdd(&counts[c], (uint32_t)__popcll(b));
+    }
+}
+
+// ---------------------------------------------------------------- generic carve
+// One thread per voxel, any grid shape, any min_views.  LUT = stream the packed table
+// instead of projecting; VM = also store the per-voxel camera bitmask (no early exit).
+template <bool LUT, bool VM>
+__global__ __launch_bounds__(kBlock) void k_carve_generic(const CarveParams p)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = j < p.n;
+    uint32_t vm = 0, cnt = 0;
+    if (valid) {
+        double X = 0, Y = 0, Z = 0;
+        if (!LUT) {
+            uint32_t ix, iy, izl;
+            decompose((uint32_t)j, p.nx, p.ny, ix, iy, izl);
+            X = p.xs[ix];
+            Y = p.ys[iy];
+            Z = p.zs[p.z0 + izl];
+        }
+        for (uint32_t c = 0; c < p.C; ++c) {
+            // Voxels that can no longer reach min_views stop early (result unchanged).
+            if (!VM && cnt + (p.C - c) < p.min_views) break;
+            int32_t off;
+            if (LUT) {
+                off = p.lut[(size_t)c * p.n + j];
+            } else {
+                double u, v;
+                project_point(p.cam[c], X, Y, Z, u, v);
+                off = pixel_offset(u, v, p.H, p.W);
+            }
+            if (off >= 0 && mask_bit(p.maskbits + (size_t)c * p.mwords, off)) {
+                vm |= 1u << c;
+                ++cnt;
+            }
+        }
+        if (VM) p.viewmask[j] = (uint16_t)vm;
+    }
+    const bool keep = valid && cnt >= p.min_views;
+    const uint64_t ballot = __ballot(keep);
+    if ((threadIdx.x & 63u) == 0) {
+        const uint64_t w = j >> 6;
+        p.words[w] = ballot;
+        if (ballot) atomicAdd(&p.tilecnt[w / kWordsPerTile], (uint32_t)__popcll(ballot));
+    }
+}
+
+// Survivor bits of a finished chunk: lane k stores sub-chunk k's ballot; one atomic per
+// chunk that has any survivor (most have none).
+template <int KSUB>
+__device__ __forceinline__ void store_chunk(const CarveParams &p, uint32_t chunk, uint32_t lane, uint32_t alive)
+{
+    uint64_t mine = 0;
+    uint32_t total = 0;
+#pragma unroll
+    for (int k = 0; k < KSUB; ++k) {
+        const uint64_t b = __ballot((alive >> k) & 1u);
+        if (lane == (uint32_t)k) mine = b;
+        total += (uint32_t)__popcll(b);
+    }
+    const uint64_t w0 = (uint64_t)chunk * KSUB;
+    if (lane < (uint32_t)KSUB) p.words[w0 + lane] = mine;
+    if (lane == 0 && total) atomicAdd(&p.tilecnt[w0 / kWordsPerTile], total);
+}
+
+// ---------------------------------------------------------------- LUT-streaming carve
+// All-views case (min_views == C).  HBM-bound: 4 B per voxel-view streamed once, in 256-B
+// fully coalesced wave loads; a sub-chunk whose 64 voxels are all dead issues no further
+// loads, a chunk whose KSUB sub-chunks are all dead leaves the camera loop.
+template <int KSUB>
+__global__ __launch_bounds__(kBlock) void k_carve_lut(const CarveParams p)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
+    const uint32_t nwaves = gridDim.x * (kBlock / 64);
+    const uint32_t nchunks = (uint32_t)((p.n + 64 * KSUB - 1) / (64 * KSUB));
+    for (uint32_t chunk = wave0; chunk < nchunks; chunk += nwaves) {
+        const uint64_t base = (uint64_t)chunk * (64 * KSUB) + lane;
+        uint32_t alive = 0;
+#pragma unroll
+        for (int k = 0; k < KSUB; ++k)
+            if (base + 64u * k < p.n) alive |= 1u << k;
+        for (uint32_t q = 0; q < p.C; ++q) {
+            const uint32_t c = p.order[q];
+            const int32_t *__restrict__ L = p.lut + (size_t)c * p.n + base;
+            const uint32_t *__restrict__ mb = p.maskbits + (size_t)c * p.mwords;
+            int32_t off[KSUB];
+#pragma unroll
+            for (int k = 0; k < KSUB; ++k) off[k] = ((alive >> k) & 1u) ? L[64 * k] : -1;
+#pragma unroll
+            for (int k = 0; k < KSUB; ++k) {
+                const bool hit = off[k] >= 0 && mask_bit(mb, off[k]);
+                if (!hit) alive &= ~(1u << k);
+            }
+            if (__ballot(alive != 0) == 0) break;
+        }
+        store_chunk<KSUB>(p, chunk, lane, alive);
+    }
+}
+
+// ---------------------------------------------------------------- fused carve
+// All-views case.  FP64-VALU-bound: coordinates regenerated from the index, projection
+// in-kernel, nothing streamed from HBM but the bit-packed masks (L2 resident).
+// NY64: ny % 64 == 0, so a sub-chunk is 64 consecutive y of one (ix, iz) column and its
+// index arithmetic is wave-uniform (scalar unit); otherwise per-lane division.
+template <int KSUB, bool NY64>
+__global__ __launch_bounds__(kBlock) void k_carve_fused(const CarveParams p)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
+    const uint32_t nwaves = gridDim.x * (kBlock / 64);
+    const uint32_t nchunks = (uint32_t)((p.n + 64 * KSUB - 1) / (64 * KSUB));
+    for (uint32_t chunk = wave0; chunk < nchunks; chunk += nwaves) {
+        const uint64_t base = (uint64_t)chunk * (64 * KSUB);
+        uint32_t alive = 0;
+        double X[KSUB], Y[KSUB], Z[KSUB];
+        if (NY64) {
+            uint32_t ix, iy, izl;                        // of the chunk's first voxel: uniform
+            decompose((uint32_t)base, p.nx, p.ny, ix, iy, izl);
+#pragma unroll
+            for (int k = 0; k < KSUB; ++k) {
+                if (base + 64u * k < p.n) {              // whole sub-chunk valid (n % 64 == 0)
+                    alive |= 1u << k;
+                    X[k] = p.xs[ix];
+                    Y[k] = p.ys[iy + lane];
+                    Z[k] = p.zs[p.z0 + izl];
+                } else {
+                    X[k] = Y[k] = Z[k] = 0.0;
+                }
+                iy += 64;
+                if (iy == p.ny) {
+                    iy = 0;
+                    if (++ix == p.nx) { ix = 0; ++izl; }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < KSUB; ++k) {
+                const uint64_t j = base + 64u * k + lane;
+                X[k] = Y[k] = Z[k] = 0.0;
+                if (j < p.n) {
+                    uint32_t ix, iy, izl;
+                    decompose((uint32_t)j, p.nx, p.ny, ix, iy, izl);
+                    alive |= 1u << k;
+                    X[k] = p.xs[ix];
+                    Y[k] = p.ys[iy];
+                    Z[k] = p.zs[p.z0 + izl];
+                }
+            }
+        }
+        for (uint32_t q = 0; q < p.C; ++q) {
+            const uint32_t c = p.order[q];
+            const uint32_t *__restrict__ mb = p.maskbits + (size_t)c * p.mwords;
+#pragma unroll
+            for (int k = 0; k < KSUB; ++k) {
+                if ((alive >> k) & 1u) {
+                    double u, v;
+                    project_point(p.cam[c], X[k], Y[k], Z[k], u, v);
+                    const int32_t off = pixel_offset(u, v, p.H, p.W);
+                    if (!(off >= 0 && mask_bit(mb, off))) alive &= ~(1u << k);
+                }
+            }
+            if (__ballot(alive != 0) == 0) break;
+        }
+        store_chunk<KSUB>(p, chunk, lane, alive);
+    }
+}
+
+// ---------------------------------------------------------------- LUT build
+__global__ __launch_bounds__(kBlock) void k_build_lut(const CarveParams p, int32_t *__restrict__ lut)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= p.n) return;
+    uint32_t ix, iy, izl;
+    decompose((uint32_t)j, p.nx, p.ny, ix, iy, izl);
+    const double X = p.xs[ix], Y = p.ys[iy], Z = p.zs[p.z0 + izl];
+    for (uint32_t c = 0; c < p.C; ++c) {
+        double u, v;
+        project_point(p.cam[c], X, Y, Z, u, v);
+        lut[(size_t)c * p.n + j] = pixel_offset(u, v, p.H, p.W);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_project(const CamDev cam, const double *__restrict__ xyz,
+                                                    uint64_t n, double *__restrict__ uv)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    double u, v;
+    project_point(cam, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], u, v);
+    uv[2 * i] = u;
+    uv[2 * i + 1] = v;
+}
+
+// ---------------------------------------------------------------- compaction
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(v, d);
+        if (lane >= (uint32_t)d) v += o;
+    }
+    return v;
+}
+
+// Exclusive scan of the tile counts inside blocks of kScanBlock tiles; the per-block
+// sums go to blocksum[] (the emit kernel and the host add them up).
+__global__ __launch_bounds__(kScanBlock) void k_scan_tiles(const uint32_t *__restrict__ cnt, uint64_t ntiles,
+                                                           uint64_t *__restrict__ off,
+                                                           uint64_t *__restrict__ blocksum)
+{
+    __shared__ uint32_t wsum[kScanBlock / 64];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint64_t i = (uint64_t)blockIdx.x * kScanBlock + t;
+    const uint32_t c = (i < ntiles) ? cnt[i] : 0u;     // <= 16384 each: a block total fits u32
+    const uint32_t incl = wave_inclusive_scan(c, lane);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kScanBlock / 64; ++k) {
+        const uint32_t s = wsum[k];
+        if (k < wave) before += s;
+        total += s;
+    }
+    if (i < ntiles) off[i] = (uint64_t)(before + incl - c);
+    if (t == 0) blocksum[blockIdx.x] = total;
+}
+
+// r-th (0-based) set bit of x; requires r < popcount(x).
+__device__ __forceinline__ uint32_t select_bit(uint64_t x, uint32_t r)
+{
+    uint32_t pos = 0;
+#pragma unroll
+    for (uint32_t s = 32; s >= 1; s >>= 1) {
+        const uint32_t c = (uint32_t)__popcll((x >> pos) & ((1ull << s) - 1ull));
+        if (r >= c) { r -= c; pos += s; }
+    }
+    return pos;
+}
+
+// One workgroup per tile, one thread per SURVIVOR (strided): ordered expansion of the
+// survivor bits into 8-byte records {idx, r, g, b, seen}, with the colour-camera sample
+// (assignment.py:133).  Writes are consecutive across the wave.
+__global__ __launch_bounds__(kBlock) void k_emit(const EmitParams p)
+{
+    __shared__ uint32_t incl_s[kBlock];
+    __shared__ uint64_t bits_s[kBlock];
+    __shared__ uint32_t wsum[kBlock / 64];
+    __shared__ uint64_t blockoff_s;
+    const uint64_t tile = blockIdx.x;
+    const uint32_t cnt = p.tilecnt[tile];
+    if (cnt == 0) return;                              // uniform per workgroup
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint64_t w = tile * kWordsPerTile + t;
+    const uint64_t nwords = (p.n + 63) >> 6;
+    const uint64_t bits = (w < nwords) ? p.words[w] : 0ull;
+    const uint32_t c = (uint32_t)__popcll(bits);
+    uint32_t incl = wave_inclusive_scan(c, lane);
+    if (lane == 63) wsum[wave] = incl;
+    if (t == 0) {                                      // survivors of all earlier scan blocks
+        uint64_t s = 0;
+        const uint64_t sb = tile / kScanBlock;
+        for (uint64_t b = 0; b < sb; ++b) s += p.blocksum[b];
+        blockoff_s = s;
+    }
+    __syncthreads();
+    for (uint32_t k = 0; k < wave; ++k) incl += wsum[k];
+    incl_s[t] = incl;
+    bits_s[t] = bits;
+    __syncthreads();
+    const uint64_t out0 = blockoff_s + p.tileoff[tile];
+    for (uint32_t k = t; k < cnt; k += kBlock) {
+        uint32_t lo = 0, hi = kBlock - 1;              // first word whose inclusive count exceeds k
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (incl_s[mid] > k) hi = mid; else lo = mid + 1;
+        }
+        const uint64_t wb = bits_s[lo];
+        const uint32_t r = k - (incl_s[lo] - (uint32_t)__popcll(wb));
+        const uint32_t j = (uint32_t)((tile * kWordsPerTile + lo) << 6) + select_bit(wb, r);
+        uint64_t rec = (uint32_t)(p.i0 + j);
+        if (p.has_cam) {
+            uint32_t ix, iy, izl;
+            decompose(j, p.nx, p.ny, ix, iy, izl);
+            double u, v;
+            project_point(p.cam, p.xs[ix], p.ys[iy], p.zs[p.z0 + izl], u, v);
+            const int32_t off = pixel_offset(u, v, p.H, p.W);
+            if (off >= 0 && p.maskbits && mask_bit(p.maskbits, off)) {
+                uint64_t rr = 0, gg = 0, bb = 0;
+                if (p.frame) {
+                    const uint8_t *px = p.frame + 3 * (size_t)off;
+                    bb = px[0]; gg = px[1]; rr = px[2];
+                }
+                rec |= (rr << 32) | (gg << 40) | (bb << 48) | (1ull << 56);
+            }
+        }
+        if (out0 + k < p.capacity) p.records[out0 + k] = rec;
+    }
+}
+
+}  // namespace vc

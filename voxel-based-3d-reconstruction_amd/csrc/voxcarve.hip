@@ -29,233 +29,13 @@
 #include <vector>
 
 #include "../../include/voxcarve.h"
-#include "vc_device.h"
+#include "vc_kernels.h"
 
 #pragma clang fp contract(off)
 
-using vc::CamDev;
+using namespace vc;
 
 namespace {
-
-constexpr uint32_t kBlock = 256;            // 4 waves of 64
-constexpr uint32_t kWordsPerTile = 256;     // 16384 voxels per compaction tile
-
-struct CarveParams {
-    const double *xs, *ys, *zs;
-    const uint32_t *maskbits;   // [C][mwords] of the active slot
-    const int32_t *lut;         // [C][n]
-    uint64_t *words;
-    uint32_t *tilecnt;
-    uint16_t *viewmask;
-    uint64_t n;                 // voxels in the slab
-    uint32_t nx, ny, nz, z0;
-    uint32_t C, H, W, mwords;
-    uint32_t min_views;
-    CamDev cam[VC_MAX_CAMERAS];
-};
-
-struct EmitParams {
-    const double *xs, *ys, *zs;
-    const uint32_t *maskbits;   // colour camera's mask of the active slot (or null)
-    const uint8_t *frame;       // colour camera's BGR image (or null)
-    const uint64_t *words;
-    const uint32_t *tilecnt;
-    const uint64_t *tileoff;
-    uint64_t *records;
-    uint64_t capacity;
-    uint64_t n;
-    uint64_t i0;                // global linear index of slab-local voxel 0
-    uint32_t nx, ny, z0;
-    uint32_t H, W;
-    int has_cam;
-    CamDev cam;
-};
-
-__device__ __forceinline__ void decompose(uint64_t j, uint32_t nx, uint32_t ny,
-                                          uint32_t &ix, uint32_t &iy, uint32_t &izl)
-{
-    const uint64_t t = j / ny;
-    iy = (uint32_t)(j - t * ny);
-    izl = (uint32_t)(t / nx);
-    ix = (uint32_t)(t - (uint64_t)izl * nx);
-}
-
-// ---------------------------------------------------------------- mask bit-packing
-// One thread per output word: 32 mask bytes -> 32 bits (foreground where byte > 0,
-// voxel_reconstruction.py:112).
-__global__ __launch_bounds__(kBlock) void k_pack_masks(const uint8_t *__restrict__ bytes,
-                                                       uint32_t *__restrict__ bits,
-                                                       uint32_t C, uint32_t HW, uint32_t mwords)
-{
-    const uint32_t w = blockIdx.x * kBlock + threadIdx.x;
-    const uint32_t c = blockIdx.y;
-    if (w >= mwords || c >= C) return;
-    const uint8_t *src = bytes + (size_t)c * HW;
-    const uint32_t p0 = w * 32u;
-    uint32_t out = 0;
-    if (p0 + 32u <= HW && ((reinterpret_cast<uintptr_t>(src + p0) & 3u) == 0)) {
-        const uint32_t *s4 = reinterpret_cast<const uint32_t *>(src + p0);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const uint32_t v = s4[q];
-            out |= ((v & 0x000000ffu) ? 1u : 0u) << (4 * q + 0);
-            out |= ((v & 0x0000ff00u) ? 1u : 0u) << (4 * q + 1);
-            out |= ((v & 0x00ff0000u) ? 1u : 0u) << (4 * q + 2);
-            out |= ((v & 0xff000000u) ? 1u : 0u) << (4 * q + 3);
-        }
-    } else {
-        for (uint32_t b = 0; b < 32u && p0 + b < HW; ++b) out |= (src[p0 + b] ? 1u : 0u) << b;
-    }
-    bits[(size_t)c * mwords + w] = out;
-}
-
-// ---------------------------------------------------------------- generic carve
-// One thread per voxel, any grid shape.  LUT = stream the packed table instead of
-// projecting; VM = also store the per-voxel camera bitmask (no early exit then).
-template <bool LUT, bool VM>
-__global__ __launch_bounds__(kBlock) void k_carve_generic(const CarveParams p)
-{
-    const uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    const bool valid = j < p.n;
-    uint32_t vm = 0, cnt = 0;
-    if (valid) {
-        double X = 0, Y = 0, Z = 0;
-        if (!LUT) {
-            uint32_t ix, iy, izl;
-            decompose(j, p.nx, p.ny, ix, iy, izl);
-            X = p.xs[ix];
-            Y = p.ys[iy];
-            Z = p.zs[p.z0 + izl];
-        }
-        for (uint32_t c = 0; c < p.C; ++c) {
-            // Voxels that can no longer reach min_views stop early (result unchanged).
-            if (!VM && cnt + (p.C - c) < p.min_views) break;
-            int32_t off;
-            if (LUT) {
-                off = p.lut[(size_t)c * p.n + j];
-            } else {
-                double u, v;
-                vc::project_point(p.cam[c], X, Y, Z, u, v);
-                off = vc::pixel_offset(u, v, p.H, p.W);
-            }
-            if (off >= 0 && vc::mask_bit(p.maskbits + (size_t)c * p.mwords, off)) {
-                vm |= 1u << c;
-                ++cnt;
-            }
-        }
-        if (VM) p.viewmask[j] = (uint16_t)vm;
-    }
-    const bool keep = valid && cnt >= p.min_views;
-    const uint64_t ballot = __ballot(keep);
-    if ((threadIdx.x & 63u) == 0) {
-        const uint64_t w = j >> 6;
-        p.words[w] = ballot;
-        if (ballot) atomicAdd(&p.tilecnt[w / kWordsPerTile], (uint32_t)__popcll(ballot));
-    }
-}
-
-// ---------------------------------------------------------------- LUT build
-__global__ __launch_bounds__(kBlock) void k_build_lut(const CarveParams p, int32_t *__restrict__ lut)
-{
-    const uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (j >= p.n) return;
-    uint32_t ix, iy, izl;
-    decompose(j, p.nx, p.ny, ix, iy, izl);
-    const double X = p.xs[ix], Y = p.ys[iy], Z = p.zs[p.z0 + izl];
-    for (uint32_t c = 0; c < p.C; ++c) {
-        double u, v;
-        vc::project_point(p.cam[c], X, Y, Z, u, v);
-        lut[(size_t)c * p.n + j] = vc::pixel_offset(u, v, p.H, p.W);
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void k_project(const CamDev cam, const double *__restrict__ xyz,
-                                                    uint64_t n, double *__restrict__ uv)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    double u, v;
-    vc::project_point(cam, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], u, v);
-    uv[2 * i] = u;
-    uv[2 * i + 1] = v;
-}
-
-// ---------------------------------------------------------------- compaction
-// Exclusive scan of the per-tile survivor counts: one workgroup, sequential chunks.
-__global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t *__restrict__ cnt,
-                                                     uint64_t *__restrict__ off, uint64_t ntiles,
-                                                     uint64_t *__restrict__ total)
-{
-    __shared__ uint64_t part[1024];
-    const uint32_t t = threadIdx.x;
-    const uint64_t per = (ntiles + 1023) / 1024;
-    const uint64_t b = t * per;
-    const uint64_t e = (b + per < ntiles) ? b + per : ntiles;
-    uint64_t s = 0;
-    for (uint64_t i = b; i < e; ++i) s += cnt[i];
-    part[t] = s;
-    __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {       // Hillis-Steele inclusive scan
-        uint64_t v = (t >= d) ? part[t - d] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    uint64_t run = part[t] - s;
-    for (uint64_t i = b; i < e; ++i) {
-        off[i] = run;
-        run += cnt[i];
-    }
-    if (t == 1023) *total = part[1023];
-}
-
-// One workgroup per tile, one thread per 64-voxel word: ordered expansion of the
-// survivor bits into records, with the colour-camera sample (assignment.py:133).
-__global__ __launch_bounds__(kBlock) void k_emit(const EmitParams p)
-{
-    __shared__ uint32_t wsum[4];
-    const uint64_t tile = blockIdx.x;
-    if (p.tilecnt[tile] == 0) return;                 // uniform per workgroup
-    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    const uint64_t w = tile * kWordsPerTile + t;
-    const uint64_t nwords = (p.n + 63) >> 6;
-    uint64_t bits = (w < nwords) ? p.words[w] : 0;
-    const uint32_t c = (uint32_t)__popcll(bits);
-    uint32_t incl = c;                                 // inclusive scan across the wave
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(incl, d);
-        if (lane >= (uint32_t)d) incl += o;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    uint32_t base = 0;
-    for (uint32_t k = 0; k < wave; ++k) base += wsum[k];
-    uint64_t pos = p.tileoff[tile] + base + (incl - c);
-    while (bits) {
-        const uint32_t b = (uint32_t)__builtin_ctzll(bits);
-        bits &= bits - 1;
-        const uint64_t j = (w << 6) + b;
-        uint64_t rec = (uint32_t)(p.i0 + j);
-        if (p.has_cam) {
-            uint32_t ix, iy, izl;
-            decompose(j, p.nx, p.ny, ix, iy, izl);
-            double u, v;
-            vc::project_point(p.cam, p.xs[ix], p.ys[iy], p.zs[p.z0 + izl], u, v);
-            const int32_t off = vc::pixel_offset(u, v, p.H, p.W);
-            if (off >= 0 && p.maskbits && vc::mask_bit(p.maskbits, off)) {
-                uint64_t r = 0, g = 0, bl = 0;
-                if (p.frame) {
-                    const uint8_t *px = p.frame + 3 * (size_t)off;
-                    bl = px[0]; g = px[1]; r = px[2];
-                }
-                rec |= (r << 32) | (g << 40) | (bl << 48) | (1ull << 56);
-            }
-        }
-        if (pos < p.capacity) p.records[pos] = rec;
-        ++pos;
-    }
-}
 
 // ================================================================ host side
 struct RcclApi {
@@ -308,6 +88,8 @@ struct Slot {
     DevBuf<uint8_t> frames;     // [C][H*W*3]
     std::vector<uint8_t> have_frame;
     bool have_masks = false;
+    uint32_t order[VC_MAX_CAMERAS];  // most selective camera first (k_estimate)
+    bool order_valid = false;
 };
 
 // np.linspace(lo, hi, num=n) in float64: y[k] = k*step + lo (two roundings), y[n-1] = hi
@@ -355,7 +137,12 @@ struct vc_ctx {
     bool lut_valid = false;
     DevBuf<uint64_t> d_words;
     DevBuf<uint32_t> d_tilecnt;
-    DevBuf<uint64_t> d_tileoff;      // + 1 slot for the total
+    DevBuf<uint64_t> d_tileoff;
+    DevBuf<uint64_t> d_blocksum;     // survivors per scan block
+    DevBuf<uint32_t> d_est;          // per-camera pass counts of k_estimate
+    uint64_t *h_blocksum = nullptr;  // pinned, kMaxScanBlocks
+    uint32_t *h_est = nullptr;       // pinned, VC_MAX_CAMERAS
+    bool force_generic = false;      // VOXCARVE_FORCE_GENERIC=1: one-thread-per-voxel kernels only
     DevBuf<uint16_t> d_viewmask;
     DevBuf<uint64_t> d_records;
     DevBuf<double> d_scratch;
@@ -455,6 +242,11 @@ int slot_at(vc_ctx *ctx, uint32_t slot, Slot **out)
 
 uint32_t grid_for(uint64_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
 
+constexpr uint32_t kMaxScanBlocks = 512;   // 2^32 voxels / 16384 per tile / 1024 tiles per scan block = 256
+constexpr int kSub = 4;                    // 64-voxel sub-chunks per wavefront chunk
+constexpr uint32_t kPersistentBlocks = 256 * 8;   // 256 CUs x 8 workgroups of 4 waves = full occupancy
+constexpr uint32_t kEstimateSamples = 1u << 16;
+
 }  // namespace
 
 // ================================================================ C ABI
@@ -492,6 +284,10 @@ int vc_create(int device, vc_ctx **out)
     hipError_t e1 = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     for (int i = 0; i < 4 && e1 == hipSuccess; ++i) e1 = hipEventCreate(&ctx->ev[i]);
     if (e1 == hipSuccess) e1 = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_total), sizeof(uint64_t), hipHostMallocDefault);
+    if (e1 == hipSuccess) e1 = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_blocksum), sizeof(uint64_t) * kMaxScanBlocks, hipHostMallocDefault);
+    if (e1 == hipSuccess) e1 = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_est), sizeof(uint32_t) * VC_MAX_CAMERAS, hipHostMallocDefault);
+    const char *fg = getenv("VOXCARVE_FORCE_GENERIC");
+    ctx->force_generic = fg && fg[0] == '1';
     if (e1 != hipSuccess) {
         int rc = fail(nullptr, VC_ERR_HIP, "context setup: %s", hipGetErrorString(e1));
         delete ctx;
@@ -512,6 +308,9 @@ int vc_destroy(vc_ctx *ctx)
     release(ctx->d_tilecnt); release(ctx->d_tileoff); release(ctx->d_viewmask);
     release(ctx->d_records); release(ctx->d_scratch); release(ctx->d_counts); release(ctx->d_gathered);
     if (ctx->h_total) (void)hipHostFree(ctx->h_total);
+    if (ctx->h_blocksum) (void)hipHostFree(ctx->h_blocksum);
+    if (ctx->h_est) (void)hipHostFree(ctx->h_est);
+    release(ctx->d_blocksum); release(ctx->d_est);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
     for (int i = 0; i < 4; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -618,6 +417,7 @@ int vc_upload_masks(vc_ctx *ctx, uint32_t slot, const uint8_t *masks)
     VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.h2d_ms, ctx->ev[0], ctx->ev[1]));
     s->have_masks = true;
+    s->order_valid = false;
     return VC_OK;
 }
 
@@ -707,9 +507,12 @@ int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int 
 
     const uint64_t nwords = (n + 63) / 64;
     const uint64_t ntiles = (nwords + kWordsPerTile - 1) / kWordsPerTile;
+    const uint32_t nscan = (uint32_t)((ntiles + kScanBlock - 1) / kScanBlock);
     VC_TRY(ensure(ctx, ctx->d_words, ntiles * kWordsPerTile));
     VC_TRY(ensure(ctx, ctx->d_tilecnt, ntiles));
-    VC_TRY(ensure(ctx, ctx->d_tileoff, ntiles + 1));
+    VC_TRY(ensure(ctx, ctx->d_tileoff, ntiles));
+    VC_TRY(ensure(ctx, ctx->d_blocksum, kMaxScanBlocks));
+    VC_TRY(ensure(ctx, ctx->d_est, VC_MAX_CAMERAS));
     if (want_vm) VC_TRY(ensure(ctx, ctx->d_viewmask, n));
     if (!ctx->d_records.ptr) VC_TRY(ensure(ctx, ctx->d_records, (size_t)(n / 16 + 1024)));
 
@@ -722,28 +525,59 @@ int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int 
     p.viewmask = ctx->d_viewmask.ptr;
     p.min_views = min_views;
 
+    // The chunked kernels cover the reference's case (seen by ALL cameras); the
+    // one-thread-per-voxel kernels cover thresholds below C and the camera bitmask.
+    const bool fast = !ctx->force_generic && !want_vm && min_views >= ctx->C;
+    if (fast && !s.order_valid) {
+        // Most selective camera first: pass counts on a strided sample of the slab.
+        VC_HIP(ctx, hipMemsetAsync(ctx->d_est.ptr, 0, sizeof(uint32_t) * VC_MAX_CAMERAS, ctx->stream));
+        const uint32_t ns = (uint32_t)(n < kEstimateSamples ? n : kEstimateSamples);
+        hipLaunchKernelGGL(k_estimate, dim3(grid_for(ns)), dim3(kBlock), 0, ctx->stream, p, ctx->d_est.ptr, ns);
+        VC_HIP(ctx, hipGetLastError());
+        VC_HIP(ctx, hipMemcpyAsync(ctx->h_est, ctx->d_est.ptr, sizeof(uint32_t) * ctx->C, hipMemcpyDeviceToHost, ctx->stream));
+        VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (uint32_t c = 0; c < ctx->C; ++c) s.order[c] = c;
+        for (uint32_t a = 1; a < ctx->C; ++a)             // stable insertion sort, ascending pass count
+            for (uint32_t b = a; b > 0 && ctx->h_est[s.order[b]] < ctx->h_est[s.order[b - 1]]; --b) {
+                const uint32_t t = s.order[b]; s.order[b] = s.order[b - 1]; s.order[b - 1] = t;
+            }
+        s.order_valid = true;
+    }
+    for (uint32_t c = 0; c < ctx->C; ++c) p.order[c] = fast ? s.order[c] : c;
+
     VC_HIP(ctx, hipMemsetAsync(ctx->d_tilecnt.ptr, 0, ntiles * sizeof(uint32_t), ctx->stream));
     VC_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    const dim3 grid(grid_for(n)), block(kBlock);
-    if (mode == VC_MODE_LUT) {
-        if (want_vm) hipLaunchKernelGGL((k_carve_generic<true, true>), grid, block, 0, ctx->stream, p);
-        else hipLaunchKernelGGL((k_carve_generic<true, false>), grid, block, 0, ctx->stream, p);
+    const dim3 block(kBlock);
+    if (fast) {
+        const uint64_t nchunks = (n + 64 * kSub - 1) / (64 * kSub);
+        const uint64_t want = (nchunks + 3) / 4;
+        const dim3 grid((uint32_t)(want < kPersistentBlocks ? want : kPersistentBlocks));
+        if (mode == VC_MODE_LUT) hipLaunchKernelGGL((k_carve_lut<kSub>), grid, block, 0, ctx->stream, p);
+        else if (ctx->ny % 64 == 0) hipLaunchKernelGGL((k_carve_fused<kSub, true>), grid, block, 0, ctx->stream, p);
+        else hipLaunchKernelGGL((k_carve_fused<kSub, false>), grid, block, 0, ctx->stream, p);
     } else {
-        if (want_vm) hipLaunchKernelGGL((k_carve_generic<false, true>), grid, block, 0, ctx->stream, p);
-        else hipLaunchKernelGGL((k_carve_generic<false, false>), grid, block, 0, ctx->stream, p);
+        const dim3 grid(grid_for(n));
+        if (mode == VC_MODE_LUT) {
+            if (want_vm) hipLaunchKernelGGL((k_carve_generic<true, true>), grid, block, 0, ctx->stream, p);
+            else hipLaunchKernelGGL((k_carve_generic<true, false>), grid, block, 0, ctx->stream, p);
+        } else {
+            if (want_vm) hipLaunchKernelGGL((k_carve_generic<false, true>), grid, block, 0, ctx->stream, p);
+            else hipLaunchKernelGGL((k_carve_generic<false, false>), grid, block, 0, ctx->stream, p);
+        }
     }
     VC_HIP(ctx, hipGetLastError());
     VC_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
 
-    uint64_t *d_total = ctx->d_tileoff.ptr + ntiles;
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_tilecnt.ptr,
-                       ctx->d_tileoff.ptr, ntiles, d_total);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(nscan), dim3(kScanBlock), 0, ctx->stream, ctx->d_tilecnt.ptr, ntiles,
+                       ctx->d_tileoff.ptr, ctx->d_blocksum.ptr);
     VC_HIP(ctx, hipGetLastError());
+    VC_HIP(ctx, hipMemcpyAsync(ctx->h_blocksum, ctx->d_blocksum.ptr, sizeof(uint64_t) * nscan, hipMemcpyDeviceToHost, ctx->stream));
 
     EmitParams e;
     memset(&e, 0, sizeof e);
     e.xs = p.xs; e.ys = p.ys; e.zs = p.zs;
     e.words = ctx->d_words.ptr; e.tilecnt = ctx->d_tilecnt.ptr; e.tileoff = ctx->d_tileoff.ptr;
+    e.blocksum = ctx->d_blocksum.ptr;
     e.n = n; e.i0 = ctx->i0(); e.nx = ctx->nx; e.ny = ctx->ny; e.z0 = ctx->z0; e.H = ctx->H; e.W = ctx->W;
     if (color_cam >= 0) {
         e.has_cam = 1;
@@ -752,19 +586,21 @@ int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int 
         if (s.frames.ptr && s.have_frame[color_cam])
             e.frame = s.frames.ptr + (size_t)color_cam * ctx->H * ctx->W * 3;
     }
+    uint64_t total = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         e.records = ctx->d_records.ptr;
         e.capacity = ctx->d_records.cap;
         hipLaunchKernelGGL(k_emit, dim3((uint32_t)ntiles), block, 0, ctx->stream, e);
         VC_HIP(ctx, hipGetLastError());
         VC_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
-        VC_HIP(ctx, hipMemcpyAsync(ctx->h_total, d_total, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
         VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (*ctx->h_total <= ctx->d_records.cap) break;
+        total = 0;
+        for (uint32_t b = 0; b < nscan; ++b) total += ctx->h_blocksum[b];
+        if (total <= ctx->d_records.cap) break;
         if (attempt == 1) return fail(ctx, VC_ERR_HIP, "survivor buffer still too small after regrow");
-        VC_TRY(ensure(ctx, ctx->d_records, (size_t)(*ctx->h_total + *ctx->h_total / 8 + 1024)));
+        VC_TRY(ensure(ctx, ctx->d_records, (size_t)(total + total / 8 + 1024)));
     }
-    ctx->survivors = *ctx->h_total;
+    ctx->survivors = total;
     float ms = 0;
     VC_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
     ctx->tm.carve_ms = ms;
