@@ -59,6 +59,8 @@ typedef struct {
     uint64_t survivors; /* survivors of the last carve (this rank)                     */
     uint32_t carve_launches; /* carve kernel launches since vc_timing_reset            */
     float carve_ms_sum; /* summed carve kernel time since vc_timing_reset              */
+    float first_ms;     /* VC_MODE_LUT: the first-camera streaming kernel of the last carve */
+    float first_ms_sum; /* summed since vc_timing_reset                                 */
 } vc_timing_t;
 
 /* ---- lifetime ------------------------------------------------------------------ */
@@ -118,6 +120,8 @@ int vc_fetch_viewmask(vc_ctx *ctx, uint16_t *viewmask);
  * slab-local voxel j (consumer shape of assignment.py:143-146). */
 int vc_fetch_occupancy(vc_ctx *ctx, uint8_t *bits);
 
+/* Tuning knobs (launch geometry; never changes results): see voxcarve.hip vc_set_option. */
+int vc_set_option(vc_ctx *ctx, const char *name, int value);
 int vc_timing(vc_ctx *ctx, vc_timing_t *out);
 int vc_timing_reset(vc_ctx *ctx);
 

@@ -33,7 +33,8 @@ class VcTiming(ctypes.Structure):
                 ("gather_ms", ctypes.c_float), ("lut_ms", ctypes.c_float),
                 ("h2d_ms", ctypes.c_float), ("voxels", ctypes.c_uint64),
                 ("survivors", ctypes.c_uint64), ("carve_launches", ctypes.c_uint32),
-                ("carve_ms_sum", ctypes.c_float)]
+                ("carve_ms_sum", ctypes.c_float), ("first_ms", ctypes.c_float),
+                ("first_ms_sum", ctypes.c_float)]
 
 
 # name -> (restype, argtypes); every symbol include/voxcarve.h declares.
@@ -59,6 +60,7 @@ SIGNATURES = {
     "vc_fetch_records": (ctypes.c_int, [c_ctx, c_u64p]),
     "vc_fetch_viewmask": (ctypes.c_int, [c_ctx, c_u16p]),
     "vc_fetch_occupancy": (ctypes.c_int, [c_ctx, c_u8p]),
+    "vc_set_option": (ctypes.c_int, [c_ctx, ctypes.c_char_p, ctypes.c_int]),
     "vc_timing": (ctypes.c_int, [c_ctx, ctypes.POINTER(VcTiming)]),
     "vc_timing_reset": (ctypes.c_int, [c_ctx]),
     "vc_comm_unique_id": (ctypes.c_int, [c_u8p]),

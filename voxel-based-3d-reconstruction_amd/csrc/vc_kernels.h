@@ -16,6 +16,7 @@ constexpr uint32_t kBlock = 256;            // 4 wavefronts
 constexpr uint32_t kWordsPerTile = 256;     // compaction tile = 16384 voxels
 constexpr uint32_t kScanBlock = 1024;       // tiles per scan workgroup
 constexpr uint32_t kMaxCameras = 16;
+constexpr uint32_t kLutPad = 4096;          // voxels; every chunking below divides it
 
 struct CarveParams {
     const double *xs, *ys, *zs;
@@ -25,6 +26,7 @@ struct CarveParams {
     uint32_t *tilecnt;
     uint16_t *viewmask;
     uint64_t n;                 // voxels in the slab (< 2^32)
+    uint64_t n_pad;             // LUT camera stride: n rounded up to kLutPad, tail entries = -1
     uint32_t nx, ny, nz, z0;
     uint32_t C, H, W, mwords;
     uint32_t min_views;
@@ -36,6 +38,7 @@ struct EmitParams {
     const double *xs, *ys, *zs;
     const uint32_t *maskbits;   // colour camera's mask bits (or null)
     const uint8_t *frame;       // colour camera's BGR image (or null)
+    const int32_t *lut;         // colour camera's packed table (FROM_LUT), else null
     const uint64_t *words;
     const uint32_t *tilecnt;
     const uint64_t *tileoff;    // exclusive scan inside each scan block
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(kBlock) void k_carve_generic(const CarveParams p)
             if (!VM && cnt + (p.C - c) < p.min_views) break;
             int32_t off;
             if (LUT) {
-                off = p.lut[(size_t)c * p.n + j];
+                off = p.lut[(size_t)c * p.n_pad + j];
             } else {
                 double u, v;
                 project_point(p.cam[c], X, Y, Z, u, v);
@@ -174,37 +177,138 @@ __device__ __forceinline__ void store_chunk(const CarveParams &p, uint32_t chunk
 }
 
 // ---------------------------------------------------------------- LUT-streaming carve
-// All-views case (min_views == C).  HBM-bound: 4 B per voxel-view streamed once, in 256-B
-// fully coalesced wave loads; a sub-chunk whose 64 voxels are all dead issues no further
-// loads, a chunk whose KSUB sub-chunks are all dead leaves the camera loop.
-template <int KSUB>
-__global__ __launch_bounds__(kBlock) void k_carve_lut(const CarveParams p)
+// All-views case (min_views == C), two launches:
+//
+//  k_lut_first   the most selective camera's table, read for EVERY voxel: a pure HBM
+//                stream (4 B per voxel, 16 B per lane per load, software-pipelined one
+//                chunk ahead) tested against that camera's bit-packed mask held in LDS
+//                (the gather would otherwise be texture-addresser bound).  Writes the
+//                alive bits, one u64 word per 64 voxels.
+//  k_lut_refine  the other cameras, only where an alive bit is left: B alive words at a
+//                time, per-lane predicated loads, so the tables are read sparsely.
+//                Writes the final words and the per-tile survivor counts.
+//
+// A lane of k_lut_first holds 4 consecutive voxels (one dwordx4), so the survivor nibbles
+// are transposed into 64-voxel words with four DPP row shifts (lane 15 of every row of 16
+// lanes ends up with the word).
+__device__ __forceinline__ uint32_t row_or_reduce(uint32_t v)
+{
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    return v;
+}
+
+constexpr uint32_t kFirstBlock = 512;
+
+template <int KV>
+__global__ __launch_bounds__(kFirstBlock) void k_lut_first(const CarveParams p)
+{
+    extern __shared__ uint32_t s_mask[];                         // first camera's mask bits
+    const uint32_t c0 = p.order[0];
+    {
+        const uint32_t *__restrict__ mb = p.maskbits + (size_t)c0 * p.mwords;
+        for (uint32_t i = threadIdx.x; i < p.mwords; i += kFirstBlock) s_mask[i] = mb[i];
+    }
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kFirstBlock + threadIdx.x) >> 6);
+    const uint32_t nwaves = gridDim.x * (kFirstBlock / 64);
+    const uint32_t nchunks = (uint32_t)(p.n_pad / (256 * KV));
+    if (wave0 >= nchunks) return;
+    const int4 *__restrict__ L = reinterpret_cast<const int4 *>(p.lut + (size_t)c0 * p.n_pad);
+
+    auto fetch = [&](uint32_t ch, int4 (&dst)[KV]) {
+        if (ch >= nchunks) ch = nchunks - 1;                     // clamped: branch-free, in bounds
+        const int4 *src = L + (size_t)ch * (64 * KV) + lane;
+#pragma unroll
+        for (int k = 0; k < KV; ++k) dst[k] = src[64 * k];
+    };
+    auto test = [&](int32_t o) -> uint32_t {
+        const uint32_t w = s_mask[o >= 0 ? ((uint32_t)o >> 5) : 0u];
+        return (o >= 0) ? ((w >> ((uint32_t)o & 31u)) & 1u) : 0u;
+    };
+
+    int4 nxt[KV];
+    fetch(wave0, nxt);
+    const uint32_t sh = (lane & 7u) * 4u;
+    const bool upper = (lane & 8u) != 0;
+    for (uint32_t chunk = wave0; chunk < nchunks; chunk += nwaves) {
+        int4 off[KV];
+#pragma unroll
+        for (int k = 0; k < KV; ++k) off[k] = nxt[k];
+        fetch(chunk + nwaves, nxt);
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+            const uint32_t nib = test(off[k].x) | (test(off[k].y) << 1) | (test(off[k].z) << 2) | (test(off[k].w) << 3);
+            const uint32_t lo = row_or_reduce(upper ? 0u : (nib << sh));
+            const uint32_t hi = row_or_reduce(upper ? (nib << sh) : 0u);
+            if ((lane & 15u) == 15u)
+                p.words[((uint64_t)chunk * KV + k) * 4 + (lane >> 4)] = ((uint64_t)hi << 32) | lo;
+        }
+    }
+}
+
+template <int B>
+__global__ __launch_bounds__(kBlock) void k_lut_refine(const CarveParams p)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
     const uint32_t nwaves = gridDim.x * (kBlock / 64);
-    const uint32_t nchunks = (uint32_t)((p.n + 64 * KSUB - 1) / (64 * KSUB));
-    for (uint32_t chunk = wave0; chunk < nchunks; chunk += nwaves) {
-        const uint64_t base = (uint64_t)chunk * (64 * KSUB) + lane;
-        uint32_t alive = 0;
-#pragma unroll
-        for (int k = 0; k < KSUB; ++k)
-            if (base + 64u * k < p.n) alive |= 1u << k;
-        for (uint32_t q = 0; q < p.C; ++q) {
-            const uint32_t c = p.order[q];
-            const int32_t *__restrict__ L = p.lut + (size_t)c * p.n + base;
-            const uint32_t *__restrict__ mb = p.maskbits + (size_t)c * p.mwords;
-            int32_t off[KSUB];
-#pragma unroll
-            for (int k = 0; k < KSUB; ++k) off[k] = ((alive >> k) & 1u) ? L[64 * k] : -1;
-#pragma unroll
-            for (int k = 0; k < KSUB; ++k) {
-                const bool hit = off[k] >= 0 && mask_bit(mb, off[k]);
-                if (!hit) alive &= ~(1u << k);
-            }
-            if (__ballot(alive != 0) == 0) break;
+    const uint32_t ngroups = (uint32_t)(p.n_pad / 4096);         // 64 words of 64 voxels
+    uint64_t next = (wave0 < ngroups) ? p.words[(uint64_t)wave0 * 64 + lane] : 0ull;
+    for (uint32_t g = wave0; g < ngroups; g += nwaves) {
+        const uint64_t gw = (uint64_t)g * 64;
+        uint64_t mine = next;
+        {
+            const uint32_t gn = (g + nwaves < ngroups) ? g + nwaves : g;   // clamped prefetch
+            next = p.words[(uint64_t)gn * 64 + lane];
         }
-        store_chunk<KSUB>(p, chunk, lane, alive);
+        uint64_t nz = __ballot(mine != 0);
+        while (p.C > 1 && nz != 0) {                              // wave-uniform
+            uint32_t li[B];
+            uint32_t alive = 0;
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                li[b] = 64;
+                if (nz != 0) {
+                    li[b] = (uint32_t)__builtin_ctzll(nz);
+                    nz &= nz - 1;
+                    const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, (int)li[b]);
+                    const uint32_t whi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), (int)li[b]);
+                    const uint64_t wv = ((uint64_t)whi << 32) | wlo;
+                    if ((wv >> lane) & 1ull) alive |= 1u << b;
+                }
+            }
+            for (uint32_t q = 1; q < p.C; ++q) {
+                const uint32_t c = p.order[q];
+                const int32_t *__restrict__ L = p.lut + (size_t)c * p.n_pad + gw * 64 + lane;
+                const uint32_t *__restrict__ mb = p.maskbits + (size_t)c * p.mwords;
+                int32_t off[B];
+                uint32_t mw[B];
+#pragma unroll
+                for (int b = 0; b < B; ++b) off[b] = ((alive >> b) & 1u) ? L[(size_t)li[b] * 64] : -1;
+#pragma unroll
+                for (int b = 0; b < B; ++b) mw[b] = (off[b] >= 0) ? mb[(uint32_t)off[b] >> 5] : 0u;
+#pragma unroll
+                for (int b = 0; b < B; ++b)
+                    if (!((mw[b] >> ((uint32_t)off[b] & 31u)) & 1u)) alive &= ~(1u << b);
+                if (__ballot(alive != 0) == 0) break;
+            }
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                if (li[b] < 64) {
+                    const uint64_t nb = __ballot((alive >> b) & 1u);
+                    if (lane == li[b]) mine = nb;
+                }
+            }
+        }
+        p.words[gw + lane] = mine;
+        uint32_t cnt = (uint32_t)__popcll(mine);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
+        if (lane == 0 && cnt) atomicAdd(&p.tilecnt[gw / kWordsPerTile], cnt);
     }
 }
 
@@ -280,14 +384,18 @@ __global__ __launch_bounds__(kBlock) void k_carve_fused(const CarveParams p)
 __global__ __launch_bounds__(kBlock) void k_build_lut(const CarveParams p, int32_t *__restrict__ lut)
 {
     const uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (j >= p.n) return;
+    if (j >= p.n_pad) return;
+    if (j >= p.n) {                                   // padding: never inside any image
+        for (uint32_t c = 0; c < p.C; ++c) lut[(size_t)c * p.n_pad + j] = -1;
+        return;
+    }
     uint32_t ix, iy, izl;
     decompose((uint32_t)j, p.nx, p.ny, ix, iy, izl);
     const double X = p.xs[ix], Y = p.ys[iy], Z = p.zs[p.z0 + izl];
     for (uint32_t c = 0; c < p.C; ++c) {
         double u, v;
         project_point(p.cam[c], X, Y, Z, u, v);
-        lut[(size_t)c * p.n + j] = pixel_offset(u, v, p.H, p.W);
+        lut[(size_t)c * p.n_pad + j] = pixel_offset(u, v, p.H, p.W);
     }
 }
 
@@ -352,60 +460,96 @@ __device__ __forceinline__ uint32_t select_bit(uint64_t x, uint32_t r)
 // One workgroup per tile, one thread per SURVIVOR (strided): ordered expansion of the
 // survivor bits into 8-byte records {idx, r, g, b, seen}, with the colour-camera sample
 // (assignment.py:133).  Writes are consecutive across the wave.
-__global__ __launch_bounds__(kBlock) void k_emit(const EmitParams p)
+constexpr uint32_t kEmitBlock = 256;
+constexpr int kEmitUnroll = 4;
+// One workgroup per tile (most are empty and exit after one scalar load; the hardware
+// dispatcher balances the busy ones); inside a tile one thread per SURVIVOR (strided):
+// ordered expansion of the survivor bits into 8-byte records {idx, r, g, b, seen} with the colour-camera sample
+// (assignment.py:133).  Record writes are consecutive across the wave.
+// ALLSEEN: every survivor is seen by every camera (min_views == C), so the colour camera's
+// test is known to pass; FROM_LUT: its pixel offset is read from the table instead of
+// being re-projected.
+template <bool FROM_LUT, bool ALLSEEN>
+__global__ __launch_bounds__(kEmitBlock) void k_emit(const EmitParams p, uint32_t ntiles)
 {
-    __shared__ uint32_t incl_s[kBlock];
-    __shared__ uint64_t bits_s[kBlock];
-    __shared__ uint32_t wsum[kBlock / 64];
-    __shared__ uint64_t blockoff_s;
-    const uint64_t tile = blockIdx.x;
-    const uint32_t cnt = p.tilecnt[tile];
-    if (cnt == 0) return;                              // uniform per workgroup
+    __shared__ uint32_t incl_s[kWordsPerTile];
+    __shared__ uint64_t bits_s[kWordsPerTile];
+    __shared__ uint32_t wsum[kWordsPerTile / 64];
+    __shared__ uint64_t bsum[kWordsPerTile / 64];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    const uint64_t w = tile * kWordsPerTile + t;
     const uint64_t nwords = (p.n + 63) >> 6;
-    const uint64_t bits = (w < nwords) ? p.words[w] : 0ull;
-    const uint32_t c = (uint32_t)__popcll(bits);
-    uint32_t incl = wave_inclusive_scan(c, lane);
-    if (lane == 63) wsum[wave] = incl;
-    if (t == 0) {                                      // survivors of all earlier scan blocks
-        uint64_t s = 0;
-        const uint64_t sb = tile / kScanBlock;
-        for (uint64_t b = 0; b < sb; ++b) s += p.blocksum[b];
-        blockoff_s = s;
-    }
-    __syncthreads();
-    for (uint32_t k = 0; k < wave; ++k) incl += wsum[k];
-    incl_s[t] = incl;
-    bits_s[t] = bits;
-    __syncthreads();
-    const uint64_t out0 = blockoff_s + p.tileoff[tile];
-    for (uint32_t k = t; k < cnt; k += kBlock) {
-        uint32_t lo = 0, hi = kBlock - 1;              // first word whose inclusive count exceeds k
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (incl_s[mid] > k) hi = mid; else lo = mid + 1;
-        }
-        const uint64_t wb = bits_s[lo];
-        const uint32_t r = k - (incl_s[lo] - (uint32_t)__popcll(wb));
-        const uint32_t j = (uint32_t)((tile * kWordsPerTile + lo) << 6) + select_bit(wb, r);
-        uint64_t rec = (uint32_t)(p.i0 + j);
-        if (p.has_cam) {
-            uint32_t ix, iy, izl;
-            decompose(j, p.nx, p.ny, ix, iy, izl);
-            double u, v;
-            project_point(p.cam, p.xs[ix], p.ys[iy], p.zs[p.z0 + izl], u, v);
-            const int32_t off = pixel_offset(u, v, p.H, p.W);
-            if (off >= 0 && p.maskbits && mask_bit(p.maskbits, off)) {
-                uint64_t rr = 0, gg = 0, bb = 0;
-                if (p.frame) {
-                    const uint8_t *px = p.frame + 3 * (size_t)off;
-                    bb = px[0]; gg = px[1]; rr = px[2];
+    {
+        const uint32_t tile = blockIdx.x;
+        const uint32_t cnt = p.tilecnt[tile];
+        if (cnt == 0) return;                              // uniform per workgroup
+        const uint64_t w = (uint64_t)tile * kWordsPerTile + t;
+        const uint64_t bits = (w < nwords) ? p.words[w] : 0ull;
+        const uint32_t c = (uint32_t)__popcll(bits);
+        uint32_t incl = wave_inclusive_scan(c, lane);
+        // survivors of all earlier scan blocks (at most 256 of them): one load per thread
+        uint64_t before = (t < tile / kScanBlock) ? p.blocksum[t] : 0ull;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d);
+        if (lane == 63) { wsum[wave] = incl; bsum[wave] = before; }
+        __syncthreads();
+        for (uint32_t k = 0; k < wave; ++k) incl += wsum[k];
+        const uint64_t blockoff = bsum[0] + bsum[1] + bsum[2] + bsum[3];
+        incl_s[t] = incl;
+        bits_s[t] = bits;
+        __syncthreads();
+        const uint64_t out0 = blockoff + p.tileoff[tile];
+        // kEmitUnroll survivors per thread and pass, phase by phase, so their dependent loads
+        // (table entry -> pixel) overlap instead of queueing behind each other.
+        for (uint32_t k0 = t; k0 < cnt; k0 += kEmitBlock * kEmitUnroll) {
+            uint32_t j[kEmitUnroll];
+            int32_t off[kEmitUnroll] = {};
+            bool live[kEmitUnroll];
+#pragma unroll
+            for (int u = 0; u < kEmitUnroll; ++u) {
+                const uint32_t k = k0 + u * kEmitBlock;
+                live[u] = k < cnt;
+                const uint32_t kk = live[u] ? k : cnt - 1;
+                uint32_t lo = 0;                           // first word whose inclusive count exceeds kk
+#pragma unroll
+                for (uint32_t step = kWordsPerTile / 2; step >= 1; step >>= 1)
+                    if (incl_s[lo + step - 1] <= kk) lo += step;
+                const uint64_t wb = bits_s[lo];
+                const uint32_t r = kk - (incl_s[lo] - (uint32_t)__popcll(wb));
+                j[u] = ((tile * kWordsPerTile + lo) << 6) + select_bit(wb, r);
+            }
+            if (p.has_cam) {
+#pragma unroll
+                for (int u = 0; u < kEmitUnroll; ++u) {
+                    if (FROM_LUT) {
+                        off[u] = p.lut[j[u]];
+                    } else {
+                        uint32_t ix, iy, izl;
+                        decompose(j[u], p.nx, p.ny, ix, iy, izl);
+                        double uu, vv;
+                        project_point(p.cam, p.xs[ix], p.ys[iy], p.zs[p.z0 + izl], uu, vv);
+                        off[u] = pixel_offset(uu, vv, p.H, p.W);
+                    }
                 }
-                rec |= (rr << 32) | (gg << 40) | (bb << 48) | (1ull << 56);
+            }
+            uint64_t rec[kEmitUnroll];
+#pragma unroll
+            for (int u = 0; u < kEmitUnroll; ++u) {
+                rec[u] = (uint32_t)(p.i0 + j[u]);
+                if (p.has_cam && (ALLSEEN || (off[u] >= 0 && p.maskbits && mask_bit(p.maskbits, off[u])))) {
+                    uint64_t rr = 0, gg = 0, bb = 0;
+                    if (p.frame) {
+                        const uint8_t *px = p.frame + 3 * (size_t)off[u];
+                        bb = px[0]; gg = px[1]; rr = px[2];
+                    }
+                    rec[u] |= (rr << 32) | (gg << 40) | (bb << 48) | (1ull << 56);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kEmitUnroll; ++u) {
+                const uint64_t o = out0 + k0 + u * kEmitBlock;
+                if (live[u] && o < p.capacity) p.records[o] = rec[u];
             }
         }
-        if (out0 + k < p.capacity) p.records[out0 + k] = rec;
     }
 }
 

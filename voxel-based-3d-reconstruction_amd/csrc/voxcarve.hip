@@ -142,7 +142,14 @@ struct vc_ctx {
     DevBuf<uint32_t> d_est;          // per-camera pass counts of k_estimate
     uint64_t *h_blocksum = nullptr;  // pinned, kMaxScanBlocks
     uint32_t *h_est = nullptr;       // pinned, VC_MAX_CAMERAS
-    bool force_generic = false;      // VOXCARVE_FORCE_GENERIC=1: one-thread-per-voxel kernels only
+    // tuning knobs (vc_set_option); defaults are the measured best on MI355X
+    bool force_generic = false;      // one-thread-per-voxel kernels only (cross-check path)
+    int first_kv = 1;                // dwordx4 loads per lane per chunk in k_lut_first: 1, 2 or 4
+    int first_blocks_per_cu = 3;     // k_lut_first workgroups (512 threads) per CU
+    int refine_b = 16;               // alive words per batch in k_lut_refine: 8 or 16
+    int refine_blocks_per_cu = 8;    // k_lut_refine workgroups (256 threads) per CU
+    int fused_blocks_per_cu = 8;     // k_carve_fused workgroups (256 threads) per CU
+    int reorder = 1;                 // visit the most selective camera first
     DevBuf<uint16_t> d_viewmask;
     DevBuf<uint64_t> d_records;
     DevBuf<double> d_scratch;
@@ -224,6 +231,7 @@ void fill_params(const vc_ctx *ctx, CarveParams &p)
     p.ys = p.xs + ctx->nx;
     p.zs = p.ys + ctx->ny;
     p.n = ctx->n_voxels();
+    p.n_pad = (p.n + kLutPad - 1) / kLutPad * kLutPad;
     p.nx = ctx->nx; p.ny = ctx->ny; p.nz = ctx->nz; p.z0 = ctx->z0;
     p.C = ctx->C; p.H = ctx->H; p.W = ctx->W; p.mwords = ctx->mwords;
     memcpy(p.cam, ctx->cams, sizeof(CamDev) * ctx->C);
@@ -243,7 +251,9 @@ int slot_at(vc_ctx *ctx, uint32_t slot, Slot **out)
 uint32_t grid_for(uint64_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
 
 constexpr uint32_t kMaxScanBlocks = 512;   // 2^32 voxels / 16384 per tile / 1024 tiles per scan block = 256
-constexpr int kSub = 4;                    // 64-voxel sub-chunks per wavefront chunk
+constexpr int kSub = 4;                    // 64-voxel sub-chunks per wavefront chunk (fused kernel)
+constexpr size_t kLdsBytes = 160 * 1024;   // LDS per CU on gfx950
+constexpr size_t kMaxFirstLds = 64 * 1024; // static limit of one workgroup's dynamic LDS without opt-in
 constexpr uint32_t kPersistentBlocks = 256 * 8;   // 256 CUs x 8 workgroups of 4 waves = full occupancy
 constexpr uint32_t kEstimateSamples = 1u << 16;
 
@@ -442,12 +452,13 @@ int vc_build_lut(vc_ctx *ctx)
     if (!ctx->have_grid || !ctx->have_cams) return fail(ctx, VC_ERR_ARG, "grid and cameras must be set before vc_build_lut");
     VC_HIP(ctx, hipSetDevice(ctx->device));
     const uint64_t n = ctx->n_voxels();
-    VC_TRY(ensure(ctx, ctx->d_lut, (size_t)n * ctx->C));
+    const uint64_t n_pad = (n + kLutPad - 1) / kLutPad * kLutPad;
+    VC_TRY(ensure(ctx, ctx->d_lut, (size_t)n_pad * ctx->C));
     if (n) {
         CarveParams p;
         fill_params(ctx, p);
         VC_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-        hipLaunchKernelGGL(k_build_lut, dim3(grid_for(n)), dim3(kBlock), 0, ctx->stream, p, ctx->d_lut.ptr);
+        hipLaunchKernelGGL(k_build_lut, dim3(grid_for(n_pad)), dim3(kBlock), 0, ctx->stream, p, ctx->d_lut.ptr);
         VC_HIP(ctx, hipGetLastError());
         VC_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
         VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -464,7 +475,8 @@ int vc_fetch_lut(vc_ctx *ctx, uint32_t cam, int32_t *out)
     if (cam >= ctx->C) return fail(ctx, VC_ERR_ARG, "camera %u not in [0,%u)", cam, ctx->C);
     VC_HIP(ctx, hipSetDevice(ctx->device));
     const uint64_t n = ctx->n_voxels();
-    if (n) VC_HIP(ctx, hipMemcpy(out, ctx->d_lut.ptr + (size_t)cam * n, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    const uint64_t n_pad = (n + kLutPad - 1) / kLutPad * kLutPad;
+    if (n) VC_HIP(ctx, hipMemcpy(out, ctx->d_lut.ptr + (size_t)cam * n_pad, n * sizeof(int32_t), hipMemcpyDeviceToHost));
     return VC_OK;
 }
 
@@ -508,7 +520,7 @@ int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int 
     const uint64_t nwords = (n + 63) / 64;
     const uint64_t ntiles = (nwords + kWordsPerTile - 1) / kWordsPerTile;
     const uint32_t nscan = (uint32_t)((ntiles + kScanBlock - 1) / kScanBlock);
-    VC_TRY(ensure(ctx, ctx->d_words, ntiles * kWordsPerTile));
+    VC_TRY(ensure(ctx, ctx->d_words, ntiles * kWordsPerTile + kLutPad / 64));
     VC_TRY(ensure(ctx, ctx->d_tilecnt, ntiles));
     VC_TRY(ensure(ctx, ctx->d_tileoff, ntiles));
     VC_TRY(ensure(ctx, ctx->d_blocksum, kMaxScanBlocks));
@@ -527,7 +539,9 @@ int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int 
 
     // The chunked kernels cover the reference's case (seen by ALL cameras); the
     // one-thread-per-voxel kernels cover thresholds below C and the camera bitmask.
-    const bool fast = !ctx->force_generic && !want_vm && min_views >= ctx->C;
+    bool fast = !ctx->force_generic && !want_vm && min_views >= ctx->C;
+    // k_lut_first keeps one camera's mask bits in LDS; larger masks take the generic kernel.
+    if (mode == VC_MODE_LUT && (size_t)ctx->mwords * sizeof(uint32_t) > kMaxFirstLds) fast = false;
     if (fast && !s.order_valid) {
         // Most selective camera first: pass counts on a strided sample of the slab.
         VC_HIP(ctx, hipMemsetAsync(ctx->d_est.ptr, 0, sizeof(uint32_t) * VC_MAX_CAMERAS, ctx->stream));
@@ -543,7 +557,7 @@ int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int 
             }
         s.order_valid = true;
     }
-    for (uint32_t c = 0; c < ctx->C; ++c) p.order[c] = fast ? s.order[c] : c;
+    for (uint32_t c = 0; c < ctx->C; ++c) p.order[c] = (fast && ctx->reorder) ? s.order[c] : c;
 
     VC_HIP(ctx, hipMemsetAsync(ctx->d_tilecnt.ptr, 0, ntiles * sizeof(uint32_t), ctx->stream));
     VC_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
@@ -551,8 +565,30 @@ int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int 
     if (fast) {
         const uint64_t nchunks = (n + 64 * kSub - 1) / (64 * kSub);
         const uint64_t want = (nchunks + 3) / 4;
-        const dim3 grid((uint32_t)(want < kPersistentBlocks ? want : kPersistentBlocks));
-        if (mode == VC_MODE_LUT) hipLaunchKernelGGL((k_carve_lut<kSub>), grid, block, 0, ctx->stream, p);
+        const uint64_t gmax = 256ull * (uint64_t)ctx->fused_blocks_per_cu;
+        const dim3 grid((uint32_t)(want < gmax ? want : gmax));
+        if (mode == VC_MODE_LUT) {
+            const size_t lds = (size_t)ctx->mwords * sizeof(uint32_t);
+            const int kv = ctx->first_kv;
+            const uint64_t chunks = p.n_pad / (256 * kv);
+            const uint64_t fwant = (chunks + 7) / 8;
+            uint32_t per_cu = (uint32_t)(kLdsBytes / (lds ? lds : 1));
+            if (per_cu > (uint32_t)ctx->first_blocks_per_cu) per_cu = (uint32_t)ctx->first_blocks_per_cu;
+            if (per_cu < 1) per_cu = 1;
+            const uint32_t fmax = 256u * per_cu;
+            const dim3 fgrid((uint32_t)(fwant < fmax ? fwant : fmax)), fblock(kFirstBlock);
+            if (kv == 1) hipLaunchKernelGGL((k_lut_first<1>), fgrid, fblock, lds, ctx->stream, p);
+            else if (kv == 4) hipLaunchKernelGGL((k_lut_first<4>), fgrid, fblock, lds, ctx->stream, p);
+            else hipLaunchKernelGGL((k_lut_first<2>), fgrid, fblock, lds, ctx->stream, p);
+            VC_HIP(ctx, hipGetLastError());
+            VC_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+            const uint64_t groups = p.n_pad / 4096;
+            const uint64_t rwant = (groups + 3) / 4;
+            const uint64_t rmax = 256ull * (uint64_t)ctx->refine_blocks_per_cu;
+            const dim3 rgrid((uint32_t)(rwant < rmax ? rwant : rmax));
+            if (ctx->refine_b == 8) hipLaunchKernelGGL((k_lut_refine<8>), rgrid, block, 0, ctx->stream, p);
+            else hipLaunchKernelGGL((k_lut_refine<16>), rgrid, block, 0, ctx->stream, p);
+        }
         else if (ctx->ny % 64 == 0) hipLaunchKernelGGL((k_carve_fused<kSub, true>), grid, block, 0, ctx->stream, p);
         else hipLaunchKernelGGL((k_carve_fused<kSub, false>), grid, block, 0, ctx->stream, p);
     } else {
@@ -585,12 +621,21 @@ int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int 
         e.maskbits = s.bits.ptr + (size_t)color_cam * ctx->mwords;
         if (s.frames.ptr && s.have_frame[color_cam])
             e.frame = s.frames.ptr + (size_t)color_cam * ctx->H * ctx->W * 3;
+        if (mode == VC_MODE_LUT) e.lut = ctx->d_lut.ptr + (size_t)color_cam * p.n_pad;
     }
     uint64_t total = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         e.records = ctx->d_records.ptr;
         e.capacity = ctx->d_records.cap;
-        hipLaunchKernelGGL(k_emit, dim3((uint32_t)ntiles), block, 0, ctx->stream, e);
+        {
+            const dim3 eg((uint32_t)ntiles), eb(kEmitBlock);
+            const uint32_t nt = (uint32_t)ntiles;
+            const bool allseen = min_views >= ctx->C;
+            if (e.lut && allseen) hipLaunchKernelGGL((k_emit<true, true>), eg, eb, 0, ctx->stream, e, nt);
+            else if (e.lut) hipLaunchKernelGGL((k_emit<true, false>), eg, eb, 0, ctx->stream, e, nt);
+            else if (allseen) hipLaunchKernelGGL((k_emit<false, true>), eg, eb, 0, ctx->stream, e, nt);
+            else hipLaunchKernelGGL((k_emit<false, false>), eg, eb, 0, ctx->stream, e, nt);
+        }
         VC_HIP(ctx, hipGetLastError());
         VC_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
         VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -604,6 +649,9 @@ int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int 
     float ms = 0;
     VC_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
     ctx->tm.carve_ms = ms;
+    ctx->tm.first_ms = 0;
+    if (fast && mode == VC_MODE_LUT) VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.first_ms, ctx->ev[0], ctx->ev[3]));
+    ctx->tm.first_ms_sum += ctx->tm.first_ms;
     ctx->tm.carve_ms_sum += ms;
     ctx->tm.carve_launches += 1;
     VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.compact_ms, ctx->ev[1], ctx->ev[2]));
@@ -661,6 +709,21 @@ int vc_fetch_occupancy(vc_ctx *ctx, uint8_t *bits)
     return VC_OK;
 }
 
+int vc_set_option(vc_ctx *ctx, const char *name, int value)
+{
+    if (!ctx || !name) return VC_ERR_ARG;
+    const std::string k(name);
+    if (k == "force_generic") ctx->force_generic = value != 0;
+    else if (k == "reorder") ctx->reorder = value != 0;
+    else if (k == "first_kv" && (value == 1 || value == 2 || value == 4)) ctx->first_kv = value;
+    else if (k == "first_blocks_per_cu" && value >= 1 && value <= 8) ctx->first_blocks_per_cu = value;
+    else if (k == "refine_b" && (value == 8 || value == 16)) ctx->refine_b = value;
+    else if (k == "refine_blocks_per_cu" && value >= 1 && value <= 16) ctx->refine_blocks_per_cu = value;
+    else if (k == "fused_blocks_per_cu" && value >= 1 && value <= 16) ctx->fused_blocks_per_cu = value;
+    else return fail(ctx, VC_ERR_ARG, "unknown option or bad value: %s = %d", name, value);
+    return VC_OK;
+}
+
 int vc_timing(vc_ctx *ctx, vc_timing_t *out)
 {
     if (!ctx || !out) return VC_ERR_ARG;
@@ -673,6 +736,7 @@ int vc_timing_reset(vc_ctx *ctx)
     if (!ctx) return VC_ERR_ARG;
     ctx->tm.carve_launches = 0;
     ctx->tm.carve_ms_sum = 0;
+    ctx->tm.first_ms_sum = 0;
     return VC_OK;
 }
 

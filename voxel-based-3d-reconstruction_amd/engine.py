@@ -165,6 +165,10 @@ class CarveEngine:
         self._check(self._L.vc_fetch_occupancy(self._ctx, _ptr(raw, ctypes.c_uint8)), "vc_fetch_occupancy")
         return np.unpackbits(raw, bitorder="little")[:n].astype(bool)
 
+    def set_option(self, name, value):
+        """Launch-geometry tuning knobs (never change results); see vc_set_option."""
+        self._check(self._L.vc_set_option(self._ctx, name.encode(), int(value)), "vc_set_option")
+
     def synchronize(self):
         self._check(self._L.vc_synchronize(self._ctx), "vc_synchronize")
 
