@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--mode", choices=("lut", "fused"), default="lut")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--e2e", action="store_true", help="also time host->device inputs + device->host records per step")
     return ap.parse_args()
 
 
@@ -247,6 +248,19 @@ def main():
         "phases_ms": {"carve_kernels": round(head["kernel_ms"], 4), "compact": round(head["compact_ms"], 4),
                       "gather": round(head["gather_ms"], 4), "lut_build_once": round(lut_ms, 3)},
     }
+    if args.e2e and grp.world == 1:
+        # PCIe-inclusive rate (never `value`): byte masks + colour frame up, carve, records down, per step.
+        rolled = [[np.roll(m, 3 * s, axis=1) for m in masks] for s in range(N_SLOTS)]
+        t0 = time.perf_counter()
+        for i in range(5):
+            eng.upload_masks(rolled[i % N_SLOTS], slot=0)
+            eng.upload_frame(1, frames[1], slot=0)
+            eng.carve(slot=0, mode=args.mode)
+            rec = eng.fetch_records()
+        dt = (time.perf_counter() - t0) / 5
+        out["pcie_inclusive"] = {"value": round(total_vv / dt / 1e6, 1), "unit": "Mvoxel-views/s",
+                                 "ms_per_step": round(dt * 1e3, 3), "bytes_down_per_step": int(rec.nbytes),
+                                 "bytes_up_per_step": int(C * H * W + H * W * 3)}
     if grp.rank == 0 and grp.world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(G, cams, masks, frames, args.cpu_seconds)
     elif grp.rank == 0:
