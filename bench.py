@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--mode", choices=("lut", "fused"), default="lut")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--transport", choices=("rccl", "host"), default="rccl",
+                    help="N>1 survivor exchange: rccl (device, default) or host (gloo; rehearsal on one GPU)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     ap.add_argument("--e2e", action="store_true", help="also time host->device inputs + device->host records per step")
     return ap.parse_args()
 
@@ -103,10 +106,13 @@ class Group:
             self.dist.destroy_process_group()
 
 
-def run_mode(eng, grp, mode, steps, warmup, multi):
+def run_mode(eng, grp, mode, steps, warmup, multi, host_transport=None):
     """W untimed + K timed steps of one mode; returns (seconds, kernel ms avg, survivors, total)."""
     def step(i):
         n = eng.carve(slot=i % N_SLOTS, mode=mode)
+        if multi and host_transport is not None:
+            _, total = host_transport.allgather_records(eng.fetch_records())
+            return n, total
         if multi:
             _, total = eng.allgather()
             return n, total
@@ -170,7 +176,7 @@ def main():
     G = args.grid
     grid = (G, G, G)
 
-    eng = voxcarve.CarveEngine(grp.local_rank)
+    eng = voxcarve.CarveEngine(0 if args.single_device else grp.local_rank)
     eng.set_grid(*grid)
     z0, z1 = slabs.slab_range(G, grp.world, grp.rank)
     eng.set_slab(z0, z1)
@@ -179,7 +185,10 @@ def main():
         eng.upload_masks([np.roll(m, 3 * s, axis=1) for m in masks], slot=s)
         eng.upload_frame(1, np.roll(frames[1], 3 * s, axis=1), slot=s)
     multi = grp.world > 1
-    if multi:
+    host_transport = None
+    if multi and args.transport == "host":
+        host_transport = slabs.TorchTransport()
+    elif multi:
         uid = grp.bcast_bytes(voxcarve.CarveEngine.comm_unique_id() if grp.rank == 0 else None)
         eng.comm_init(grp.world, grp.rank, uid)
     eng.build_lut()
@@ -188,7 +197,7 @@ def main():
     results = {}
     order = [args.mode] + [m for m in ("lut", "fused") if m != args.mode]
     for mode in order:
-        dt, kernel_ms, n_local, n_total, tm = run_mode(eng, grp, mode, args.steps, args.warmup, multi)
+        dt, kernel_ms, n_local, n_total, tm = run_mode(eng, grp, mode, args.steps, args.warmup, multi, host_transport)
         results[mode] = {"seconds": dt, "kernel_ms": kernel_ms, "survivors": int(n_total),
                          "compact_ms": tm["compact_ms"], "gather_ms": tm["gather_ms"], "tm": tm}
 
@@ -239,7 +248,7 @@ def main():
         "data": "reference calibration (4x config.xml) + frame-0 MOG mask fixtures rolled per step; synthetic colour frames",
         "config": {"workload": "%d^3 voxel grid x %d cams (%dx%d masks), z-slab split over %d GPU(s), mode=%s, "
                                "ordered survivor list + colour%s" % (G, C, W, H, grp.world, args.mode,
-                                                                     " + RCCL all-gather" if multi else ""),
+                                                                     (" + RCCL all-gather" if host_transport is None else " + host (gloo) gather") if multi else ""),
                    "grid": [G, G, G], "cameras": C, "mode": args.mode, "survivors": head["survivors"]},
         "roofline": roof,
         "other_mode": {"mode": other, "value": round(total_vv * args.steps / o["seconds"] / 1e6, 1),
@@ -251,12 +260,14 @@ def main():
     if args.e2e and grp.world == 1:
         # PCIe-inclusive rate (never `value`): byte masks + colour frame up, carve, records down, per step.
         rolled = [[np.roll(m, 3 * s, axis=1) for m in masks] for s in range(N_SLOTS)]
+        eng.carve(slot=0, mode=args.mode)
+        eng.fetch_records(pinned=True)          # allocate the page-locked read-back buffer once
         t0 = time.perf_counter()
         for i in range(5):
             eng.upload_masks(rolled[i % N_SLOTS], slot=0)
             eng.upload_frame(1, frames[1], slot=0)
             eng.carve(slot=0, mode=args.mode)
-            rec = eng.fetch_records()
+            rec = eng.fetch_records(pinned=True)
         dt = (time.perf_counter() - t0) / 5
         out["pcie_inclusive"] = {"value": round(total_vv / dt / 1e6, 1), "unit": "Mvoxel-views/s",
                                  "ms_per_step": round(dt * 1e3, 3), "bytes_down_per_step": int(rec.nbytes),

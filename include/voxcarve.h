@@ -114,6 +114,9 @@ int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int 
 int vc_fetch(vc_ctx *ctx, uint32_t *idx, uint8_t *rgb, uint8_t *seen);
 /* Raw 8-byte records {u32 idx, u8 r, g, b, seen} of the last carve (S of them). */
 int vc_fetch_records(vc_ctx *ctx, uint64_t *records);
+/* Page-locked host buffers for the fetch destinations (PCIe-rate read-back). */
+int vc_host_alloc(vc_ctx *ctx, uint64_t bytes, void **out);
+int vc_host_free(vc_ctx *ctx, void *ptr);
 /* Per-voxel camera bitmask u16 [n] of the last carve run with VC_FLAG_VIEWMASK. */
 int vc_fetch_viewmask(vc_ctx *ctx, uint16_t *viewmask);
 /* Dense occupancy of the last carve: ceil(n/64)*8 bytes, bit (j & 7) of byte j >> 3 for

@@ -139,6 +139,34 @@ def test_random_scenes_ragged_shapes(eng, seed):
                     assert np.array_equal(eng.fetch_viewmask(), want["viewmask"])
 
 
+def test_config5_shape_16_cameras_1080p(eng):
+    """BASELINE config 5 inputs (16 synthetic ring cameras, 1080x1920 masks, colour on) at an
+    oracle-sized grid: masks too large for the LDS path, 16-bit camera bitmask, all modes."""
+    from voxcarve import synthetic
+    from oracle import carve_c
+    H, W, C = 1080, 1920, 16
+    scams = synthetic.ring_cameras(C, H, W)
+    smasks = synthetic.ellipsoid_masks(scams, H, W)
+    sframes = synthetic.random_frames(C, H, W)
+    grid = (48, 64, 40)
+    want = carve_c.carve(*grid, fx.oracle_cams(scams), smasks, sframes, color_cam=5, want_viewmask=True)
+    assert want["count"] > 100
+    eng.set_grid(*grid)
+    eng.set_cameras(scams, H, W)
+    eng.upload_masks(smasks)
+    eng.upload_frame(5, sframes[5])
+    eng.build_lut()
+    for mode in ("fused", "lut"):
+        assert eng.carve(mode=mode, color_cam=5) == want["count"]
+        idx, rgb, seen = eng.fetch()
+        assert np.array_equal(idx, want["idx"]) and np.array_equal(rgb[:, ::-1], want["bgr"]) and seen.all()
+        eng.carve(mode=mode, color_cam=5, viewmask=True, min_views=1)
+        assert np.array_equal(eng.fetch_viewmask(), want["viewmask"])
+    want12 = carve_c.carve(*grid, fx.oracle_cams(scams), smasks, sframes, color_cam=5, min_views=12)
+    assert eng.carve(mode="fused", color_cam=5, min_views=12) == want12["count"] > want["count"]
+    assert np.array_equal(eng.fetch()[0], want12["idx"])
+
+
 def test_all_background_and_all_foreground(eng, cams, masks):
     from oracle import carve_c
     H, W = masks[0].shape
@@ -180,6 +208,7 @@ def test_rccl_allgather_single_rank(eng, cams, masks, frames):
     n = eng.carve()
     uid = voxcarve.CarveEngine.comm_unique_id()
     eng.comm_init(1, 0, uid)
+    assert np.array_equal(eng.fetch_records(pinned=True), eng.fetch_records())     # page-locked read-back path
     counts, total = eng.allgather()
     assert counts.tolist() == [n] and total == n
     assert np.array_equal(eng.fetch_gathered(), eng.fetch_records())

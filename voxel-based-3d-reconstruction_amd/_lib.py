@@ -58,6 +58,8 @@ SIGNATURES = {
                                 ctypes.c_uint32, c_u64p]),
     "vc_fetch": (ctypes.c_int, [c_ctx, c_u32p, c_u8p, c_u8p]),
     "vc_fetch_records": (ctypes.c_int, [c_ctx, c_u64p]),
+    "vc_host_alloc": (ctypes.c_int, [c_ctx, ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p)]),
+    "vc_host_free": (ctypes.c_int, [c_ctx, ctypes.c_void_p]),
     "vc_fetch_viewmask": (ctypes.c_int, [c_ctx, c_u16p]),
     "vc_fetch_occupancy": (ctypes.c_int, [c_ctx, c_u8p]),
     "vc_set_option": (ctypes.c_int, [c_ctx, ctypes.c_char_p, ctypes.c_int]),

@@ -662,6 +662,25 @@ int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int 
     return VC_OK;
 }
 
+// Page-locked host memory for the caller's output buffers: device-to-host copies into it run
+// at PCIe rate instead of the pageable-memory rate (the reference has no counterpart; its
+// outputs are Python lists).
+int vc_host_alloc(vc_ctx *ctx, uint64_t bytes, void **out)
+{
+    if (!ctx || !out) return VC_ERR_ARG;
+    *out = nullptr;
+    VC_HIP(ctx, hipSetDevice(ctx->device));
+    VC_HIP(ctx, hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return VC_OK;
+}
+
+int vc_host_free(vc_ctx *ctx, void *ptr)
+{
+    if (!ctx) return VC_ERR_ARG;
+    if (ptr) VC_HIP(ctx, hipHostFree(ptr));
+    return VC_OK;
+}
+
 int vc_fetch_records(vc_ctx *ctx, uint64_t *records)
 {
     if (!ctx || !records) return VC_ERR_ARG;

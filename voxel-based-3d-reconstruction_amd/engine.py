@@ -38,6 +38,7 @@ class CarveEngine:
     # -- lifetime -----------------------------------------------------------------
     def close(self):
         if self._ctx:
+            self._release_pinned()
             self._L.vc_destroy(self._ctx)
             self._ctx = _lib.c_ctx()
 
@@ -148,10 +149,30 @@ class CarveEngine:
                                      _ptr(seen, ctypes.c_uint8)), "vc_fetch")
         return idx, rgb, seen.astype(bool)
 
-    def fetch_records(self):
-        rec = np.empty(self.count, dtype=np.uint64)
-        self._check(self._L.vc_fetch_records(self._ctx, _ptr(rec, ctypes.c_uint64)), "vc_fetch_records")
-        return rec
+    def fetch_records(self, pinned=False):
+        """u64 records of the last carve.  pinned=True returns a view of a page-locked buffer
+        owned by the engine (valid until the next pinned fetch): PCIe-rate read-back."""
+        if not pinned:
+            rec = np.empty(self.count, dtype=np.uint64)
+            self._check(self._L.vc_fetch_records(self._ctx, _ptr(rec, ctypes.c_uint64)), "vc_fetch_records")
+            return rec
+        need = max(self.count, 1) * 8
+        if getattr(self, "_pin_bytes", 0) < need:
+            self._release_pinned()
+            ptr = ctypes.c_void_p()
+            grow = (need + need // 4 + 7) // 8 * 8
+            self._check(self._L.vc_host_alloc(self._ctx, grow, ctypes.byref(ptr)), "vc_host_alloc")
+            self._pin_ptr, self._pin_bytes = ptr, grow
+            self._pin_arr = np.frombuffer((ctypes.c_uint8 * grow).from_address(ptr.value), dtype=np.uint64)
+        out = self._pin_arr[:self.count]
+        self._check(self._L.vc_fetch_records(self._ctx, _ptr(out, ctypes.c_uint64)), "vc_fetch_records")
+        return out
+
+    def _release_pinned(self):
+        if getattr(self, "_pin_bytes", 0):
+            self._pin_arr = None
+            self._L.vc_host_free(self._ctx, self._pin_ptr)
+            self._pin_bytes = 0
 
     def fetch_viewmask(self):
         vm = np.empty(self.n_voxels, dtype=np.uint16)
