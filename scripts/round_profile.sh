@@ -18,7 +18,7 @@ for f in glob.glob(out + "/stats/*/*kernel_stats.csv"):
 agg = collections.defaultdict(lambda: [0, 0.0])
 for f in sorted(glob.glob(out + "/pmc_*/*/*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        k = (r["Kernel_Name"].split("(")[0][-40:], r["Counter_Name"])
+        k = (r["Kernel_Name"].split("(")[0][-44:], r["Counter_Name"])
         agg[k][0] += 1; agg[k][1] += float(r["Counter_Value"])
 rows = {}
 for (kn, cn), (n, v) in sorted(agg.items()):
@@ -26,4 +26,15 @@ for (kn, cn), (n, v) in sorted(agg.items()):
         print("%-42s %-18s calls=%3d avg=%.6g" % (kn, cn, n, v / n))
         rows.setdefault(kn, {})[cn] = v / n
 json.dump(rows, open(out + "/pmc_summary.json", "w"), indent=1)
+# HBM bytes per launch of the dominant kernels (FETCH_SIZE doubled: profiles/r01_fetch_size_calibration.txt)
+traffic = {}
+for key, needle in (("lut_1024_g1", "k_lut_refine<8, true"), ("lut_stream_1024_g1", "k_lut_first")):
+    for kn, d in rows.items():
+        if needle in kn and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+            rd, wr = d["FETCH_SIZE"] * 1024 * 2, d["WRITE_SIZE"] * 1024
+            traffic[key] = {"kernel": kn.strip(), "hbm_read_bytes": rd, "hbm_write_bytes": wr, "hbm_bytes": rd + wr,
+                            "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, KB per launch; "
+                                      "FETCH_SIZE x2 (gfx950 correction, calibrated in profiles/r01_fetch_size_calibration.txt)"}
+json.dump(traffic, open(out + "/traffic.json", "w"), indent=1)
+print(json.dumps(traffic, indent=1))
 PY

@@ -14,11 +14,11 @@ eng.upload_masks(masks); eng.upload_frame(1, frames[1])
 if mode == "lut":
     eng.build_lut()
 if mode == "lut":
-    variants = [dict(first_kv=kv, first_blocks_per_cu=b) for kv in (1, 2, 4) for b in (2, 3, 4)]
-    variants += [dict(first_kv=2, first_blocks_per_cu=4, refine_b=rb, refine_blocks_per_cu=rc) for rb in (8, 16) for rc in (4, 8, 12)]
+    variants = [dict(lut_hier=0)]
+    variants += [dict(lut_hier=1, refine_wl=1, refine_b=rb, refine_blocks_per_cu=rc) for rb in (8, 16) for rc in (48, 64, 96, 128, 192, 256)]
 else:
     variants = [dict(fused_blocks_per_cu=b) for b in (4, 6, 8, 12, 16)]
-defaults = dict(first_kv=2, first_blocks_per_cu=4, refine_b=16, refine_blocks_per_cu=8, fused_blocks_per_cu=8)
+defaults = dict(first_kv=1, first_blocks_per_cu=3, refine_b=16, refine_blocks_per_cu=8, fused_blocks_per_cu=8, lut_hier=1, refine_wl=2)
 res = {i: [] for i in range(len(variants))}
 for rnd in range(5):
     for i, v in enumerate(variants):

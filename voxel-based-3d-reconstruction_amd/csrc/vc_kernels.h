@@ -16,12 +16,16 @@ constexpr uint32_t kBlock = 256;            // 4 wavefronts
 constexpr uint32_t kWordsPerTile = 256;     // compaction tile = 16384 voxels
 constexpr uint32_t kScanBlock = 1024;       // tiles per scan workgroup
 constexpr uint32_t kMaxCameras = 16;
-constexpr uint32_t kLutPad = 4096;          // voxels; every chunking below divides it
+constexpr uint32_t kLutPad = 8192;          // voxels; every chunking below divides it
+constexpr uint64_t kEmptyBox = ~0ull;       // pixel box of a word with no in-image voxel
 
 struct CarveParams {
     const double *xs, *ys, *zs;
     const uint32_t *maskbits;   // [C][mwords] of the active frame set
-    const int32_t *lut;         // [C][n]
+    const int32_t *lut;         // [C][n_pad]
+    const uint64_t *bbox;       // [C][n_pad/64] pixel bounding box of each 64-voxel word (u16 u0,v0,u1,v1)
+    const uint32_t *blockgrid;  // [C][gh][gws] "any foreground in this 2^gshift-pixel block" bits of the frame set
+    uint32_t gshift, gws, gh;   // block-grid geometry
     uint64_t *words;
     uint32_t *tilecnt;
     uint16_t *viewmask;
@@ -250,38 +254,120 @@ __global__ __launch_bounds__(kFirstBlock) void k_lut_first(const CarveParams p)
     }
 }
 
-template <int B>
+// Does the block grid of one camera hold any foreground inside pixel box `bb`?  Conservative
+// (block granularity); boxes taller than 8 or wider than 64 blocks count as "maybe".
+__device__ __forceinline__ bool box_may_hit(const uint32_t *__restrict__ g, uint64_t bb,
+                                            uint32_t gshift, uint32_t gws)
+{
+    if (bb == kEmptyBox) return false;
+    const uint32_t bu0 = (uint32_t)(bb & 0xffffu) >> gshift, bv0 = (uint32_t)((bb >> 16) & 0xffffu) >> gshift;
+    const uint32_t bu1 = (uint32_t)((bb >> 32) & 0xffffu) >> gshift, bv1 = (uint32_t)(bb >> 48) >> gshift;
+    if (bv1 - bv0 > 7u || bu1 - bu0 > 63u) return true;
+    const uint32_t w0 = bu0 >> 5, w1 = bu1 >> 5;
+    uint32_t any = 0;
+    for (uint32_t r = bv0; r <= bv1; ++r) {
+        const uint32_t *row = g + (size_t)r * gws;
+        for (uint32_t w = w0; w <= w1; ++w) {
+            uint32_t m = 0xffffffffu;
+            if (w == w0) m &= 0xffffffffu << (bu0 & 31u);
+            if (w == w1) m &= 0xffffffffu >> (31u - (bu1 & 31u));
+            any |= row[w] & m;
+        }
+    }
+    return any != 0;
+}
+
+// HIER = false: refines the alive words k_lut_first left, cameras order[1..].
+// HIER = true : no first pass at all -- a word becomes a candidate only if, for EVERY camera,
+//               the block grid (LDS) has foreground inside the word's pixel box; candidates
+//               then take the exact per-voxel test through all cameras.  Exact: a box with no
+//               foreground block cannot contain a foreground pixel of any of its voxels.
+template <int B, bool HIER, int WL>
 __global__ __launch_bounds__(kBlock) void k_lut_refine(const CarveParams p)
 {
+    extern __shared__ uint32_t s_grid[];                          // HIER: [C][gh][gws]
+    if (HIER) {
+        const uint32_t total = p.C * p.gh * p.gws;
+        for (uint32_t i = threadIdx.x; i < total; i += kBlock) s_grid[i] = p.blockgrid[i];
+        __syncthreads();
+    }
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
     const uint32_t nwaves = gridDim.x * (kBlock / 64);
-    const uint32_t ngroups = (uint32_t)(p.n_pad / 4096);         // 64 words of 64 voxels
-    uint64_t next = (wave0 < ngroups) ? p.words[(uint64_t)wave0 * 64 + lane] : 0ull;
+    constexpr uint32_t GW = 64 * WL;                              // words per group (WL per lane)
+    const uint32_t ngroups = (uint32_t)(p.n_pad / (64 * GW));
+    const uint64_t nwords = p.n_pad >> 6;
+    const uint32_t qfirst = HIER ? 0u : 1u;
+    uint64_t next[WL];
+    if (!HIER) {
+#pragma unroll
+        for (int w = 0; w < WL; ++w) next[w] = (wave0 < ngroups) ? p.words[(uint64_t)wave0 * GW + 64 * w + lane] : 0ull;
+    }
     for (uint32_t g = wave0; g < ngroups; g += nwaves) {
-        const uint64_t gw = (uint64_t)g * 64;
-        uint64_t mine = next;
-        {
+        const uint64_t gw = (uint64_t)g * GW;                     // first word of the group
+        uint64_t mine[WL];
+        if (HIER) {
+            // coarse pass: WL words per lane, four cameras' boxes in flight at a time
+            bool cand[WL];
+#pragma unroll
+            for (int w = 0; w < WL; ++w) cand[w] = true;
+            for (uint32_t q0 = 0; q0 < p.C; q0 += 4) {
+                bool any = false;
+#pragma unroll
+                for (int w = 0; w < WL; ++w) any = any || cand[w];
+                if (__ballot(any) == 0) break;
+                uint64_t bb[WL][4];
+#pragma unroll
+                for (int w = 0; w < WL; ++w)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        bb[w][k] = (q0 + k < p.C) ? p.bbox[(size_t)p.order[q0 + k] * nwords + gw + 64 * w + lane] : 0ull;
+#pragma unroll
+                for (int w = 0; w < WL; ++w)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (q0 + k < p.C && cand[w])
+                            cand[w] = box_may_hit(s_grid + (size_t)p.order[q0 + k] * p.gh * p.gws, bb[w][k], p.gshift, p.gws);
+            }
+            // a candidate word starts with every voxel of the slab alive (padding excluded)
+#pragma unroll
+            for (int w = 0; w < WL; ++w) {
+                const uint64_t j0 = (gw + 64 * w + lane) << 6;
+                mine[w] = 0;
+                if (cand[w] && j0 < p.n) mine[w] = (p.n - j0 >= 64) ? ~0ull : ((1ull << (p.n - j0)) - 1ull);
+            }
+        } else {
             const uint32_t gn = (g + nwaves < ngroups) ? g + nwaves : g;   // clamped prefetch
-            next = p.words[(uint64_t)gn * 64 + lane];
+#pragma unroll
+            for (int w = 0; w < WL; ++w) {
+                mine[w] = next[w];
+                next[w] = p.words[(uint64_t)gn * GW + 64 * w + lane];
+            }
         }
-        uint64_t nz = __ballot(mine != 0);
-        while (p.C > 1 && nz != 0) {                              // wave-uniform
-            uint32_t li[B];
+        uint64_t nz[WL];
+        bool more = false;
+#pragma unroll
+        for (int w = 0; w < WL; ++w) { nz[w] = __ballot(mine[w] != 0); more = more || nz[w] != 0; }
+        while (p.C > qfirst && more) {                            // wave-uniform
+            uint32_t li[B];                                       // 64*w + lane of the word, or ~0u
             uint32_t alive = 0;
 #pragma unroll
             for (int b = 0; b < B; ++b) {
-                li[b] = 64;
-                if (nz != 0) {
-                    li[b] = (uint32_t)__builtin_ctzll(nz);
-                    nz &= nz - 1;
-                    const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, (int)li[b]);
-                    const uint32_t whi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), (int)li[b]);
-                    const uint64_t wv = ((uint64_t)whi << 32) | wlo;
-                    if ((wv >> lane) & 1ull) alive |= 1u << b;
+                li[b] = ~0u;
+#pragma unroll
+                for (int w = 0; w < WL; ++w) {
+                    if (li[b] == ~0u && nz[w] != 0) {
+                        const uint32_t l = (uint32_t)__builtin_ctzll(nz[w]);
+                        nz[w] &= nz[w] - 1;
+                        li[b] = 64u * w + l;
+                        const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine[w], (int)l);
+                        const uint32_t whi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine[w] >> 32), (int)l);
+                        const uint64_t wv = ((uint64_t)whi << 32) | wlo;
+                        if ((wv >> lane) & 1ull) alive |= 1u << b;
+                    }
                 }
             }
-            for (uint32_t q = 1; q < p.C; ++q) {
+            for (uint32_t q = qfirst; q < p.C; ++q) {
                 const uint32_t c = p.order[q];
                 const int32_t *__restrict__ L = p.lut + (size_t)c * p.n_pad + gw * 64 + lane;
                 const uint32_t *__restrict__ mb = p.maskbits + (size_t)c * p.mwords;
@@ -298,14 +384,23 @@ __global__ __launch_bounds__(kBlock) void k_lut_refine(const CarveParams p)
             }
 #pragma unroll
             for (int b = 0; b < B; ++b) {
-                if (li[b] < 64) {
+                if (li[b] != ~0u) {
                     const uint64_t nb = __ballot((alive >> b) & 1u);
-                    if (lane == li[b]) mine = nb;
+#pragma unroll
+                    for (int w = 0; w < WL; ++w)
+                        if (li[b] == 64u * w + lane) mine[w] = nb;
                 }
             }
+            more = false;
+#pragma unroll
+            for (int w = 0; w < WL; ++w) more = more || nz[w] != 0;
         }
-        p.words[gw + lane] = mine;
-        uint32_t cnt = (uint32_t)__popcll(mine);
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int w = 0; w < WL; ++w) {
+            p.words[gw + 64 * w + lane] = mine[w];
+            cnt += (uint32_t)__popcll(mine[w]);
+        }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
         if (lane == 0 && cnt) atomicAdd(&p.tilecnt[gw / kWordsPerTile], cnt);
@@ -381,22 +476,70 @@ __global__ __launch_bounds__(kBlock) void k_carve_fused(const CarveParams p)
 }
 
 // ---------------------------------------------------------------- LUT build
-__global__ __launch_bounds__(kBlock) void k_build_lut(const CarveParams p, int32_t *__restrict__ lut)
+// create_lookup_table: every camera, every voxel of the slab.  Also reduces, per camera and
+// 64-voxel word, the bounding box of the pixels its in-image voxels land on (u16 x 4); the
+// hierarchical carve rejects whole words whose box holds no foreground.
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 {
-    const uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (j >= p.n_pad) return;
-    if (j >= p.n) {                                   // padding: never inside any image
-        for (uint32_t c = 0; c < p.C; ++c) lut[(size_t)c * p.n_pad + j] = -1;
-        return;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(v, d); v = o < v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(v, d); v = o > v ? o : v; }
+    return v;
+}
+
+__global__ __launch_bounds__(kBlock) void k_build_lut(const CarveParams p, int32_t *__restrict__ lut,
+                                                      uint64_t *__restrict__ bbox)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x;      // grid covers n_pad exactly
+    const bool valid = j < p.n;
+    double X = 0, Y = 0, Z = 0;
+    if (valid) {
+        uint32_t ix, iy, izl;
+        decompose((uint32_t)j, p.nx, p.ny, ix, iy, izl);
+        X = p.xs[ix]; Y = p.ys[iy]; Z = p.zs[p.z0 + izl];
     }
-    uint32_t ix, iy, izl;
-    decompose((uint32_t)j, p.nx, p.ny, ix, iy, izl);
-    const double X = p.xs[ix], Y = p.ys[iy], Z = p.zs[p.z0 + izl];
+    const uint64_t nwords = p.n_pad >> 6;
     for (uint32_t c = 0; c < p.C; ++c) {
-        double u, v;
-        project_point(p.cam[c], X, Y, Z, u, v);
-        lut[(size_t)c * p.n_pad + j] = pixel_offset(u, v, p.H, p.W);
+        int32_t off = -1;                             // padding: never inside any image
+        if (valid) {
+            double u, v;
+            project_point(p.cam[c], X, Y, Z, u, v);
+            off = pixel_offset(u, v, p.H, p.W);
+        }
+        lut[(size_t)c * p.n_pad + j] = off;
+        const uint32_t pv = off >= 0 ? (uint32_t)off / p.W : 0u;
+        const uint32_t pu = off >= 0 ? (uint32_t)off - pv * p.W : 0u;
+        const uint32_t u0 = wave_min_u32(off >= 0 ? pu : 0xffffu), u1 = wave_max_u32(pu);
+        const uint32_t v0 = wave_min_u32(off >= 0 ? pv : 0xffffu), v1 = wave_max_u32(pv);
+        if ((threadIdx.x & 63u) == 0)
+            bbox[(size_t)c * nwords + (j >> 6)] =
+                (u0 == 0xffffu) ? kEmptyBox : ((uint64_t)u0 | ((uint64_t)v0 << 16) | ((uint64_t)u1 << 32) | ((uint64_t)v1 << 48));
     }
+}
+
+// "Any foreground pixel in this block" bits of one frame set (blocks of 2^gshift pixels).
+__global__ __launch_bounds__(kBlock) void k_blockgrid(const uint32_t *__restrict__ maskbits, uint32_t *__restrict__ grid,
+                                                      uint32_t H, uint32_t W, uint32_t mwords,
+                                                      uint32_t gshift, uint32_t gws, uint32_t gh)
+{
+    const uint32_t c = blockIdx.y;
+    const uint32_t gw = (W + (1u << gshift) - 1) >> gshift;
+    const uint32_t b = blockIdx.x * kBlock + threadIdx.x;
+    if (b >= gw * gh) return;
+    const uint32_t bv = b / gw, bu = b - bv * gw;
+    const uint32_t *mb = maskbits + (size_t)c * mwords;
+    bool any = false;
+    for (uint32_t y = bv << gshift; y < ((bv + 1) << gshift) && y < H && !any; ++y)
+        for (uint32_t x = bu << gshift; x < ((bu + 1) << gshift) && x < W; ++x) {
+            const uint32_t o = y * W + x;
+            if ((mb[o >> 5] >> (o & 31u)) & 1u) { any = true; break; }
+        }
+    if (any) atomicOr(&grid[((size_t)c * gh + bv) * gws + (bu >> 5)], 1u << (bu & 31u));
 }
 
 __global__ __launch_bounds__(kBlock) void k_project(const CamDev cam, const double *__restrict__ xyz,

@@ -88,6 +88,7 @@ struct Slot {
     DevBuf<uint8_t> frames;     // [C][H*W*3]
     std::vector<uint8_t> have_frame;
     bool have_masks = false;
+    DevBuf<uint32_t> grid;      // [C][gh][gws] foreground-block bits (hierarchical LUT carve)
     uint32_t order[VC_MAX_CAMERAS];  // most selective camera first (k_estimate)
     bool order_valid = false;
 };
@@ -134,6 +135,8 @@ struct vc_ctx {
     DevBuf<uint8_t> d_stage;         // H2D staging for byte masks
 
     DevBuf<int32_t> d_lut;
+    DevBuf<uint64_t> d_bbox;         // [C][n_pad/64] per-word pixel boxes (built with the LUT)
+    uint32_t gshift = 2, gws = 1, gh = 1;   // block grid geometry for H x W
     bool lut_valid = false;
     DevBuf<uint64_t> d_words;
     DevBuf<uint32_t> d_tilecnt;
@@ -146,10 +149,13 @@ struct vc_ctx {
     bool force_generic = false;      // one-thread-per-voxel kernels only (cross-check path)
     int first_kv = 1;                // dwordx4 loads per lane per chunk in k_lut_first: 1, 2 or 4
     int first_blocks_per_cu = 3;     // k_lut_first workgroups (512 threads) per CU
-    int refine_b = 16;               // alive words per batch in k_lut_refine: 8 or 16
+    int refine_b = 8;                // alive words per batch in k_lut_refine: 8 or 16
     int refine_blocks_per_cu = 8;    // k_lut_refine workgroups (256 threads) per CU
     int fused_blocks_per_cu = 8;     // k_carve_fused workgroups (256 threads) per CU
     int reorder = 1;                 // visit the most selective camera first
+    int refine_wl = 1;               // words per lane in the hierarchical kernel's groups: 1 or 2
+    int hier_blocks_per_cu = 48;     // hierarchical kernel: oversubscribed grid, the dispatcher balances uneven groups
+    int lut_hier = 1;                // VC_MODE_LUT: hierarchical kernel (boxes + block grid) instead of stream + refine
     DevBuf<uint16_t> d_viewmask;
     DevBuf<uint64_t> d_records;
     DevBuf<double> d_scratch;
@@ -235,6 +241,8 @@ void fill_params(const vc_ctx *ctx, CarveParams &p)
     p.nx = ctx->nx; p.ny = ctx->ny; p.nz = ctx->nz; p.z0 = ctx->z0;
     p.C = ctx->C; p.H = ctx->H; p.W = ctx->W; p.mwords = ctx->mwords;
     memcpy(p.cam, ctx->cams, sizeof(CamDev) * ctx->C);
+    p.bbox = ctx->d_bbox.ptr;
+    p.gshift = ctx->gshift; p.gws = ctx->gws; p.gh = ctx->gh;
 }
 
 int slot_at(vc_ctx *ctx, uint32_t slot, Slot **out)
@@ -313,8 +321,8 @@ int vc_destroy(vc_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
-    for (Slot &s : ctx->slots) { release(s.bits); release(s.frames); }
-    release(ctx->d_axes); release(ctx->d_stage); release(ctx->d_lut); release(ctx->d_words);
+    for (Slot &s : ctx->slots) { release(s.bits); release(s.frames); release(s.grid); }
+    release(ctx->d_axes); release(ctx->d_stage); release(ctx->d_lut); release(ctx->d_bbox); release(ctx->d_words);
     release(ctx->d_tilecnt); release(ctx->d_tileoff); release(ctx->d_viewmask);
     release(ctx->d_records); release(ctx->d_scratch); release(ctx->d_counts); release(ctx->d_gathered);
     if (ctx->h_total) (void)hipHostFree(ctx->h_total);
@@ -399,10 +407,17 @@ int vc_set_cameras(vc_ctx *ctx, uint32_t C, const double *K9, const double *dist
     const bool reshaped = (C != ctx->C || H != ctx->H || W != ctx->W);
     ctx->C = C; ctx->H = H; ctx->W = W;
     ctx->mwords = (uint32_t)(((uint64_t)H * W + 31) / 32);
+    // foreground-block grid: finest power-of-two block whose C grids fit 48 KB of LDS
+    for (ctx->gshift = 2; ctx->gshift < 12; ++ctx->gshift) {
+        const uint32_t gw = (W + (1u << ctx->gshift) - 1) >> ctx->gshift;
+        ctx->gh = (H + (1u << ctx->gshift) - 1) >> ctx->gshift;
+        ctx->gws = (gw + 31) / 32;
+        if ((size_t)C * ctx->gh * ctx->gws * sizeof(uint32_t) <= 48 * 1024) break;
+    }
     ctx->have_cams = true;
     if (reshaped) {
         (void)hipSetDevice(ctx->device);
-        for (Slot &s : ctx->slots) { release(s.bits); release(s.frames); s.have_masks = false; s.have_frame.clear(); }
+        for (Slot &s : ctx->slots) { release(s.bits); release(s.frames); release(s.grid); s.have_masks = false; s.have_frame.clear(); }
     }
     ctx->lut_valid = false; ctx->carved = false; ctx->gathered = false; ctx->viewmask_valid = false;
     return VC_OK;
@@ -423,6 +438,16 @@ int vc_upload_masks(vc_ctx *ctx, uint32_t slot, const uint8_t *masks)
     hipLaunchKernelGGL(k_pack_masks, grid, dim3(kBlock), 0, ctx->stream, ctx->d_stage.ptr, s->bits.ptr,
                        ctx->C, (uint32_t)HW, ctx->mwords);
     VC_HIP(ctx, hipGetLastError());
+    {
+        const size_t gwords = (size_t)ctx->C * ctx->gh * ctx->gws;
+        VC_TRY(ensure(ctx, s->grid, gwords));
+        VC_HIP(ctx, hipMemsetAsync(s->grid.ptr, 0, gwords * sizeof(uint32_t), ctx->stream));
+        const uint32_t gw = (ctx->W + (1u << ctx->gshift) - 1) >> ctx->gshift;
+        dim3 gg((gw * ctx->gh + kBlock - 1) / kBlock, ctx->C);
+        hipLaunchKernelGGL(k_blockgrid, gg, dim3(kBlock), 0, ctx->stream, s->bits.ptr, s->grid.ptr, ctx->H, ctx->W,
+                           ctx->mwords, ctx->gshift, ctx->gws, ctx->gh);
+        VC_HIP(ctx, hipGetLastError());
+    }
     VC_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.h2d_ms, ctx->ev[0], ctx->ev[1]));
@@ -454,11 +479,12 @@ int vc_build_lut(vc_ctx *ctx)
     const uint64_t n = ctx->n_voxels();
     const uint64_t n_pad = (n + kLutPad - 1) / kLutPad * kLutPad;
     VC_TRY(ensure(ctx, ctx->d_lut, (size_t)n_pad * ctx->C));
+    VC_TRY(ensure(ctx, ctx->d_bbox, (size_t)(n_pad / 64) * ctx->C));
     if (n) {
         CarveParams p;
         fill_params(ctx, p);
         VC_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-        hipLaunchKernelGGL(k_build_lut, dim3(grid_for(n_pad)), dim3(kBlock), 0, ctx->stream, p, ctx->d_lut.ptr);
+        hipLaunchKernelGGL(k_build_lut, dim3(grid_for(n_pad)), dim3(kBlock), 0, ctx->stream, p, ctx->d_lut.ptr, ctx->d_bbox.ptr);
         VC_HIP(ctx, hipGetLastError());
         VC_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
         VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -532,6 +558,7 @@ int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int 
     fill_params(ctx, p);
     p.maskbits = s.bits.ptr;
     p.lut = ctx->d_lut.ptr;
+    p.blockgrid = s.grid.ptr;
     p.words = ctx->d_words.ptr;
     p.tilecnt = ctx->d_tilecnt.ptr;
     p.viewmask = ctx->d_viewmask.ptr;
@@ -541,7 +568,7 @@ int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int 
     // one-thread-per-voxel kernels cover thresholds below C and the camera bitmask.
     bool fast = !ctx->force_generic && !want_vm && min_views >= ctx->C;
     // k_lut_first keeps one camera's mask bits in LDS; larger masks take the generic kernel.
-    if (mode == VC_MODE_LUT && (size_t)ctx->mwords * sizeof(uint32_t) > kMaxFirstLds) fast = false;
+    if (mode == VC_MODE_LUT && !ctx->lut_hier && (size_t)ctx->mwords * sizeof(uint32_t) > kMaxFirstLds) fast = false;
     if (fast && !s.order_valid) {
         // Most selective camera first: pass counts on a strided sample of the slab.
         VC_HIP(ctx, hipMemsetAsync(ctx->d_est.ptr, 0, sizeof(uint32_t) * VC_MAX_CAMERAS, ctx->stream));
@@ -567,7 +594,20 @@ int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int 
         const uint64_t want = (nchunks + 3) / 4;
         const uint64_t gmax = 256ull * (uint64_t)ctx->fused_blocks_per_cu;
         const dim3 grid((uint32_t)(want < gmax ? want : gmax));
-        if (mode == VC_MODE_LUT) {
+        if (mode == VC_MODE_LUT && ctx->lut_hier) {
+            // one launch: word-level rejection by pixel box x foreground-block grid, exact test for the rest
+            const size_t lds = (size_t)ctx->C * ctx->gh * ctx->gws * sizeof(uint32_t);
+            const int wl = ctx->refine_wl;
+            const uint64_t groups = p.n_pad / (4096 * wl);
+            const uint64_t rwant = (groups + 3) / 4;
+            const uint64_t rmax = 256ull * (uint64_t)ctx->hier_blocks_per_cu;
+            const dim3 rgrid((uint32_t)(rwant < rmax ? rwant : rmax));
+            if (ctx->refine_b == 8 && wl == 1) hipLaunchKernelGGL((k_lut_refine<8, true, 1>), rgrid, block, lds, ctx->stream, p);
+            else if (ctx->refine_b == 8) hipLaunchKernelGGL((k_lut_refine<8, true, 2>), rgrid, block, lds, ctx->stream, p);
+            else if (wl == 1) hipLaunchKernelGGL((k_lut_refine<16, true, 1>), rgrid, block, lds, ctx->stream, p);
+            else hipLaunchKernelGGL((k_lut_refine<16, true, 2>), rgrid, block, lds, ctx->stream, p);
+            VC_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+        } else if (mode == VC_MODE_LUT) {
             const size_t lds = (size_t)ctx->mwords * sizeof(uint32_t);
             const int kv = ctx->first_kv;
             const uint64_t chunks = p.n_pad / (256 * kv);
@@ -586,8 +626,8 @@ int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int 
             const uint64_t rwant = (groups + 3) / 4;
             const uint64_t rmax = 256ull * (uint64_t)ctx->refine_blocks_per_cu;
             const dim3 rgrid((uint32_t)(rwant < rmax ? rwant : rmax));
-            if (ctx->refine_b == 8) hipLaunchKernelGGL((k_lut_refine<8>), rgrid, block, 0, ctx->stream, p);
-            else hipLaunchKernelGGL((k_lut_refine<16>), rgrid, block, 0, ctx->stream, p);
+            if (ctx->refine_b == 8) hipLaunchKernelGGL((k_lut_refine<8, false, 1>), rgrid, block, 0, ctx->stream, p);
+            else hipLaunchKernelGGL((k_lut_refine<16, false, 1>), rgrid, block, 0, ctx->stream, p);
         }
         else if (ctx->ny % 64 == 0) hipLaunchKernelGGL((k_carve_fused<kSub, true>), grid, block, 0, ctx->stream, p);
         else hipLaunchKernelGGL((k_carve_fused<kSub, false>), grid, block, 0, ctx->stream, p);
@@ -734,10 +774,13 @@ int vc_set_option(vc_ctx *ctx, const char *name, int value)
     const std::string k(name);
     if (k == "force_generic") ctx->force_generic = value != 0;
     else if (k == "reorder") ctx->reorder = value != 0;
+    else if (k == "lut_hier") ctx->lut_hier = value != 0;
+    else if (k == "refine_wl" && (value == 1 || value == 2)) ctx->refine_wl = value;
+    else if (k == "hier_blocks_per_cu" && value >= 1 && value <= 4096) ctx->hier_blocks_per_cu = value;
     else if (k == "first_kv" && (value == 1 || value == 2 || value == 4)) ctx->first_kv = value;
     else if (k == "first_blocks_per_cu" && value >= 1 && value <= 8) ctx->first_blocks_per_cu = value;
     else if (k == "refine_b" && (value == 8 || value == 16)) ctx->refine_b = value;
-    else if (k == "refine_blocks_per_cu" && value >= 1 && value <= 16) ctx->refine_blocks_per_cu = value;
+    else if (k == "refine_blocks_per_cu" && value >= 1 && value <= 64) ctx->refine_blocks_per_cu = value;
     else if (k == "fused_blocks_per_cu" && value >= 1 && value <= 16) ctx->fused_blocks_per_cu = value;
     else return fail(ctx, VC_ERR_ARG, "unknown option or bad value: %s = %d", name, value);
     return VC_OK;
