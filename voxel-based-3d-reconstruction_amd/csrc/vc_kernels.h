@@ -13,8 +13,8 @@
 namespace vc {
 
 constexpr uint32_t kBlock = 256;            // 4 wavefronts
-constexpr uint32_t kWordsPerTile = 256;     // compaction tile = 16384 voxels
-constexpr uint32_t kScanBlock = 1024;       // tiles per scan workgroup
+constexpr uint32_t kGroupWords = 64;        // compaction group = 64 words = 4096 voxels (one word per lane)
+constexpr uint32_t kScanBlock = 1024;       // groups per scan workgroup
 constexpr uint32_t kMaxCameras = 16;
 constexpr uint32_t kLutPad = 8192;          // voxels; every chunking below divides it
 constexpr uint64_t kEmptyBox = ~0ull;       // pixel box of a word with no in-image voxel
@@ -27,7 +27,7 @@ struct CarveParams {
     const uint32_t *blockgrid;  // [C][gh][gws] "any foreground in this 2^gshift-pixel block" bits of the frame set
     uint32_t gshift, gws, gh;   // block-grid geometry
     uint64_t *words;
-    uint32_t *tilecnt;
+    uint32_t *groupcnt;         // survivors per group of 64 words (kernels that know it write it)
     uint16_t *viewmask;
     uint64_t n;                 // voxels in the slab (< 2^32)
     uint64_t n_pad;             // LUT camera stride: n rounded up to kLutPad, tail entries = -1
@@ -41,16 +41,17 @@ struct CarveParams {
 struct EmitParams {
     const double *xs, *ys, *zs;
     const uint32_t *maskbits;   // colour camera's mask bits (or null)
-    const uint8_t *frame;       // colour camera's BGR image (or null)
+    const uint32_t *frame;      // colour camera's image as one BGRX dword per pixel (or null)
     const int32_t *lut;         // colour camera's packed table (FROM_LUT), else null
     const uint64_t *words;
-    const uint32_t *tilecnt;
-    const uint64_t *tileoff;    // exclusive scan inside each scan block
-    const uint64_t *blocksum;   // survivors per scan block
+    const uint32_t *groupcnt;   // survivors per group
+    const uint32_t *groupoff;   // exclusive scan of groupcnt inside each scan block
+    const uint64_t *blockoff;   // exclusive scan of the scan blocks' sums
     uint64_t *records;
     uint64_t capacity;
     uint64_t n;
     uint64_t i0;                // global linear index of slab-local voxel 0
+    uint32_t ngroups;
     uint32_t nx, ny, z0;
     uint32_t H, W;
     int has_cam;
@@ -155,29 +156,20 @@ __global__ __launch_bounds__(kBlock) void k_carve_generic(const CarveParams p)
     }
     const bool keep = valid && cnt >= p.min_views;
     const uint64_t ballot = __ballot(keep);
-    if ((threadIdx.x & 63u) == 0) {
-        const uint64_t w = j >> 6;
-        p.words[w] = ballot;
-        if (ballot) atomicAdd(&p.tilecnt[w / kWordsPerTile], (uint32_t)__popcll(ballot));
-    }
+    if ((threadIdx.x & 63u) == 0) p.words[j >> 6] = ballot;
 }
 
-// Survivor bits of a finished chunk: lane k stores sub-chunk k's ballot; one atomic per
-// chunk that has any survivor (most have none).
+// Survivor bits of a finished chunk: lane k stores sub-chunk k's ballot.
 template <int KSUB>
 __device__ __forceinline__ void store_chunk(const CarveParams &p, uint32_t chunk, uint32_t lane, uint32_t alive)
 {
     uint64_t mine = 0;
-    uint32_t total = 0;
 #pragma unroll
     for (int k = 0; k < KSUB; ++k) {
         const uint64_t b = __ballot((alive >> k) & 1u);
         if (lane == (uint32_t)k) mine = b;
-        total += (uint32_t)__popcll(b);
     }
-    const uint64_t w0 = (uint64_t)chunk * KSUB;
-    if (lane < (uint32_t)KSUB) p.words[w0 + lane] = mine;
-    if (lane == 0 && total) atomicAdd(&p.tilecnt[w0 / kWordsPerTile], total);
+    if (lane < (uint32_t)KSUB) p.words[(uint64_t)chunk * KSUB + lane] = mine;
 }
 
 // ---------------------------------------------------------------- LUT-streaming carve
@@ -395,15 +387,14 @@ __global__ __launch_bounds__(kBlock) void k_lut_refine(const CarveParams p)
 #pragma unroll
             for (int w = 0; w < WL; ++w) more = more || nz[w] != 0;
         }
-        uint32_t cnt = 0;
 #pragma unroll
         for (int w = 0; w < WL; ++w) {
             p.words[gw + 64 * w + lane] = mine[w];
-            cnt += (uint32_t)__popcll(mine[w]);
-        }
+            uint32_t cnt = (uint32_t)__popcll(mine[w]);
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
-        if (lane == 0 && cnt) atomicAdd(&p.tilecnt[gw / kWordsPerTile], cnt);
+            for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
+            if (lane == 0) p.groupcnt[(uint64_t)g * WL + w] = cnt;
+        }
     }
 }
 
@@ -554,6 +545,8 @@ __global__ __launch_bounds__(kBlock) void k_project(const CamDev cam, const doub
 }
 
 // ---------------------------------------------------------------- compaction
+// Ordered compaction without a sort: survivors per 64-word group -> exclusive scan (two
+// levels) -> one wave per group expands its words into records.
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane)
 {
 #pragma unroll
@@ -564,16 +557,28 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, uint32_t lan
     return v;
 }
 
-// Exclusive scan of the tile counts inside blocks of kScanBlock tiles; the per-block
-// sums go to blocksum[] (the emit kernel and the host add them up).
-__global__ __launch_bounds__(kScanBlock) void k_scan_tiles(const uint32_t *__restrict__ cnt, uint64_t ntiles,
-                                                           uint64_t *__restrict__ off,
-                                                           uint64_t *__restrict__ blocksum)
+// For the kernels that do not write groupcnt themselves (fused, generic): one wave per group.
+__global__ __launch_bounds__(kBlock) void k_count_groups(const uint64_t *__restrict__ words, uint64_t nwords,
+                                                         uint32_t ngroups, uint32_t *__restrict__ groupcnt)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t g = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    if (g >= ngroups) return;
+    const uint64_t w = (uint64_t)g * kGroupWords + lane;
+    uint32_t cnt = (w < nwords) ? (uint32_t)__popcll(words[w]) : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
+    if (lane == 0) groupcnt[g] = cnt;
+}
+
+// Level 1: exclusive scan of the group counts inside blocks of kScanBlock groups.
+__global__ __launch_bounds__(kScanBlock) void k_scan_groups(const uint32_t *__restrict__ cnt, uint32_t ngroups,
+                                                            uint32_t *__restrict__ off, uint64_t *__restrict__ blocksum)
 {
     __shared__ uint32_t wsum[kScanBlock / 64];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    const uint64_t i = (uint64_t)blockIdx.x * kScanBlock + t;
-    const uint32_t c = (i < ntiles) ? cnt[i] : 0u;     // <= 16384 each: a block total fits u32
+    const uint32_t i = blockIdx.x * kScanBlock + t;
+    const uint32_t c = (i < ngroups) ? cnt[i] : 0u;      // <= 4096 each: a block total fits u32
     const uint32_t incl = wave_inclusive_scan(c, lane);
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
@@ -584,8 +589,43 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_tiles(const uint32_t *__res
         if (k < wave) before += s;
         total += s;
     }
-    if (i < ntiles) off[i] = (uint64_t)(before + incl - c);
+    if (i < ngroups) off[i] = before + incl - c;
     if (t == 0) blocksum[blockIdx.x] = total;
+}
+
+// Level 2: exclusive scan of the (at most kScanBlock) block sums; blockoff[nblocks] = total.
+__global__ __launch_bounds__(kScanBlock) void k_scan_blocks(const uint64_t *__restrict__ blocksum, uint32_t nblocks,
+                                                            uint64_t *__restrict__ blockoff)
+{
+    __shared__ uint64_t wsum[kScanBlock / 64];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint64_t c = (t < nblocks) ? blocksum[t] : 0ull;
+    uint64_t incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t o = __shfl_up(incl, d);
+        if (lane >= (uint32_t)d) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint64_t before = 0, total = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kScanBlock / 64; ++k) {
+        const uint64_t s = wsum[k];
+        if (k < wave) before += s;
+        total += s;
+    }
+    if (t < nblocks) blockoff[t] = before + incl - c;
+    if (t == 0) blockoff[nblocks] = total;
+}
+
+// BGR bytes -> one BGRX dword per pixel, so a colour sample is a single aligned load.
+__global__ __launch_bounds__(kBlock) void k_expand_frame(const uint8_t *__restrict__ bgr, uint32_t *__restrict__ out,
+                                                         uint32_t npix)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= npix) return;
+    out[i] = (uint32_t)bgr[3 * i] | ((uint32_t)bgr[3 * i + 1] << 8) | ((uint32_t)bgr[3 * i + 2] << 16);
 }
 
 // r-th (0-based) set bit of x; requires r < popcount(x).
@@ -600,69 +640,54 @@ __device__ __forceinline__ uint32_t select_bit(uint64_t x, uint32_t r)
     return pos;
 }
 
-// One workgroup per tile, one thread per SURVIVOR (strided): ordered expansion of the
-// survivor bits into 8-byte records {idx, r, g, b, seen}, with the colour-camera sample
-// (assignment.py:133).  Writes are consecutive across the wave.
-constexpr uint32_t kEmitBlock = 256;
-constexpr int kEmitUnroll = 4;
-// One workgroup per tile (most are empty and exit after one scalar load; the hardware
-// dispatcher balances the busy ones); inside a tile one thread per SURVIVOR (strided):
-// ordered expansion of the survivor bits into 8-byte records {idx, r, g, b, seen} with the colour-camera sample
-// (assignment.py:133).  Record writes are consecutive across the wave.
-// ALLSEEN: every survivor is seen by every camera (min_views == C), so the colour camera's
-// test is known to pass; FROM_LUT: its pixel offset is read from the table instead of
-// being re-projected.
-template <bool FROM_LUT, bool ALLSEEN>
-__global__ __launch_bounds__(kEmitBlock) void k_emit(const EmitParams p, uint32_t ntiles)
+// One wave per group of 64 words (one word per lane), one lane per SURVIVOR: survivor k of
+// the group finds its word by a 6-step search over the lanes' inclusive popcounts (cross-lane
+// reads, no LDS arrays, no barriers) and its voxel by a 6-step bit select, so every load and
+// store runs with all 64 lanes busy.  EU survivors per lane are in flight together so that
+// the dependent loads (table entry -> pixel) overlap.  Record = {u32 idx, r, g, b, seen}
+// (assignment.py:133).  ALLSEEN: every survivor is seen by every camera (min_views == C), so
+// the colour camera's test is known to pass; FROM_LUT: its pixel offset is read from the table
+// instead of being re-projected.
+template <bool FROM_LUT, bool ALLSEEN, int EU>
+__global__ __launch_bounds__(kBlock) void k_emit_words(const EmitParams p)
 {
-    __shared__ uint32_t incl_s[kWordsPerTile];
-    __shared__ uint64_t bits_s[kWordsPerTile];
-    __shared__ uint32_t wsum[kWordsPerTile / 64];
-    __shared__ uint64_t bsum[kWordsPerTile / 64];
-    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    // One wave per group, no loop: the grid is the group list and the hardware dispatcher
+    // balances the busy groups of the compact hull; an empty group (5 of 6) costs its wave one
+    // scalar load of the group count.
+    const uint32_t g = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
+    if (g >= p.ngroups) return;
+    if (p.groupcnt[g] == 0) return;
     const uint64_t nwords = (p.n + 63) >> 6;
+    const uint64_t out0 = p.blockoff[g / kScanBlock] + p.groupoff[g];
     {
-        const uint32_t tile = blockIdx.x;
-        const uint32_t cnt = p.tilecnt[tile];
-        if (cnt == 0) return;                              // uniform per workgroup
-        const uint64_t w = (uint64_t)tile * kWordsPerTile + t;
-        const uint64_t bits = (w < nwords) ? p.words[w] : 0ull;
-        const uint32_t c = (uint32_t)__popcll(bits);
-        uint32_t incl = wave_inclusive_scan(c, lane);
-        // survivors of all earlier scan blocks (at most 256 of them): one load per thread
-        uint64_t before = (t < tile / kScanBlock) ? p.blocksum[t] : 0ull;
+        const uint64_t gw = (uint64_t)g * kGroupWords;
+        const uint64_t mine = (gw + lane < nwords) ? p.words[gw + lane] : 0ull;
+        const uint32_t c = (uint32_t)__popcll(mine);
+        const uint32_t incl = wave_inclusive_scan(c, lane);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        const uint32_t mlo = (uint32_t)mine, mhi = (uint32_t)(mine >> 32);
+        for (uint32_t k0 = 0; k0 < total; k0 += 64 * EU) {           // wave-uniform
+            uint32_t j[EU];
+            bool live[EU];
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d);
-        if (lane == 63) { wsum[wave] = incl; bsum[wave] = before; }
-        __syncthreads();
-        for (uint32_t k = 0; k < wave; ++k) incl += wsum[k];
-        const uint64_t blockoff = bsum[0] + bsum[1] + bsum[2] + bsum[3];
-        incl_s[t] = incl;
-        bits_s[t] = bits;
-        __syncthreads();
-        const uint64_t out0 = blockoff + p.tileoff[tile];
-        // kEmitUnroll survivors per thread and pass, phase by phase, so their dependent loads
-        // (table entry -> pixel) overlap instead of queueing behind each other.
-        for (uint32_t k0 = t; k0 < cnt; k0 += kEmitBlock * kEmitUnroll) {
-            uint32_t j[kEmitUnroll];
-            int32_t off[kEmitUnroll] = {};
-            bool live[kEmitUnroll];
+            for (int u = 0; u < EU; ++u) {
+                const uint32_t k = k0 + 64 * u + lane;
+                live[u] = k < total;
+                const uint32_t kk = live[u] ? k : total - 1;
+                uint32_t lo = 0;                                      // first lane whose inclusive count exceeds kk
 #pragma unroll
-            for (int u = 0; u < kEmitUnroll; ++u) {
-                const uint32_t k = k0 + u * kEmitBlock;
-                live[u] = k < cnt;
-                const uint32_t kk = live[u] ? k : cnt - 1;
-                uint32_t lo = 0;                           // first word whose inclusive count exceeds kk
-#pragma unroll
-                for (uint32_t step = kWordsPerTile / 2; step >= 1; step >>= 1)
-                    if (incl_s[lo + step - 1] <= kk) lo += step;
-                const uint64_t wb = bits_s[lo];
-                const uint32_t r = kk - (incl_s[lo] - (uint32_t)__popcll(wb));
-                j[u] = ((tile * kWordsPerTile + lo) << 6) + select_bit(wb, r);
+                for (uint32_t step = 32; step >= 1; step >>= 1)
+                    if ((uint32_t)__shfl((int)incl, (int)(lo + step - 1)) <= kk) lo += step;
+                const uint64_t wb = ((uint64_t)(uint32_t)__shfl((int)mhi, (int)lo) << 32) | (uint32_t)__shfl((int)mlo, (int)lo);
+                const uint32_t before = (uint32_t)__shfl((int)(incl - c), (int)lo);
+                j[u] = (uint32_t)((gw + lo) << 6) + select_bit(wb, kk - before);
             }
-            if (p.has_cam) {
+            int32_t off[EU];
 #pragma unroll
-                for (int u = 0; u < kEmitUnroll; ++u) {
+            for (int u = 0; u < EU; ++u) {
+                off[u] = -1;
+                if (p.has_cam) {
                     if (FROM_LUT) {
                         off[u] = p.lut[j[u]];
                     } else {
@@ -674,22 +699,18 @@ __global__ __launch_bounds__(kEmitBlock) void k_emit(const EmitParams p, uint32_
                     }
                 }
             }
-            uint64_t rec[kEmitUnroll];
+            uint64_t rec[EU];
 #pragma unroll
-            for (int u = 0; u < kEmitUnroll; ++u) {
+            for (int u = 0; u < EU; ++u) {
                 rec[u] = (uint32_t)(p.i0 + j[u]);
-                if (p.has_cam && (ALLSEEN || (off[u] >= 0 && p.maskbits && mask_bit(p.maskbits, off[u])))) {
-                    uint64_t rr = 0, gg = 0, bb = 0;
-                    if (p.frame) {
-                        const uint8_t *px = p.frame + 3 * (size_t)off[u];
-                        bb = px[0]; gg = px[1]; rr = px[2];
-                    }
-                    rec[u] |= (rr << 32) | (gg << 40) | (bb << 48) | (1ull << 56);
+                if (off[u] >= 0 && (ALLSEEN || (p.maskbits && mask_bit(p.maskbits, off[u])))) {
+                    const uint64_t px = p.frame ? (uint64_t)p.frame[off[u]] : 0ull;       // B | G<<8 | R<<16
+                    rec[u] |= ((px >> 16) & 0xffull) << 32 | ((px >> 8) & 0xffull) << 40 | (px & 0xffull) << 48 | (1ull << 56);
                 }
             }
 #pragma unroll
-            for (int u = 0; u < kEmitUnroll; ++u) {
-                const uint64_t o = out0 + k0 + u * kEmitBlock;
+            for (int u = 0; u < EU; ++u) {
+                const uint64_t o = out0 + k0 + 64 * u + lane;
                 if (live[u] && o < p.capacity) p.records[o] = rec[u];
             }
         }

@@ -12,8 +12,8 @@
 //   frames    u8  [slot][C][H*W*3]              BGR, only the colour camera is read
 //   lut       i32 [C][n]                        pixel offset or -1 (VC_MODE_LUT)
 //   words     u64 [ceil(n/64)]                  survivor bit per voxel (= dense occupancy)
-//   tilecnt   u32 [ceil(words/256)]             survivors per 16384-voxel tile
-//   tileoff   u64 [tiles]                       exclusive scan of tilecnt
+//   groupcnt  u32 [n_pad/4096]                  survivors per group of 64 words
+//   groupoff  u32 [groups], blockoff u64        two-level exclusive scan of groupcnt
 //   records   u64 [S]                           {u32 idx, r, g, b, seen}, ascending idx
 //
 // There is no CPU path in this library: without a GPU vc_create fails (VC_ERR_NODEV).
@@ -85,7 +85,7 @@ struct DevBuf {
 
 struct Slot {
     DevBuf<uint32_t> bits;      // [C][mwords]
-    DevBuf<uint8_t> frames;     // [C][H*W*3]
+    DevBuf<uint32_t> frames;    // [C][H*W] BGRX, one dword per pixel
     std::vector<uint8_t> have_frame;
     bool have_masks = false;
     DevBuf<uint32_t> grid;      // [C][gh][gws] foreground-block bits (hierarchical LUT carve)
@@ -139,11 +139,11 @@ struct vc_ctx {
     uint32_t gshift = 2, gws = 1, gh = 1;   // block grid geometry for H x W
     bool lut_valid = false;
     DevBuf<uint64_t> d_words;
-    DevBuf<uint32_t> d_tilecnt;
-    DevBuf<uint64_t> d_tileoff;
+    DevBuf<uint32_t> d_groupcnt;
+    DevBuf<uint32_t> d_groupoff;
+    DevBuf<uint64_t> d_blockoff;     // exclusive scan of the block sums, [nscan] = total
     DevBuf<uint64_t> d_blocksum;     // survivors per scan block
     DevBuf<uint32_t> d_est;          // per-camera pass counts of k_estimate
-    uint64_t *h_blocksum = nullptr;  // pinned, kMaxScanBlocks
     uint32_t *h_est = nullptr;       // pinned, VC_MAX_CAMERAS
     // tuning knobs (vc_set_option); defaults are the measured best on MI355X
     bool force_generic = false;      // one-thread-per-voxel kernels only (cross-check path)
@@ -258,12 +258,13 @@ int slot_at(vc_ctx *ctx, uint32_t slot, Slot **out)
 
 uint32_t grid_for(uint64_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
 
-constexpr uint32_t kMaxScanBlocks = 512;   // 2^32 voxels / 16384 per tile / 1024 tiles per scan block = 256
+constexpr uint32_t kMaxScanBlocks = 1024;  // 2^32 voxels / 4096 per group / 1024 groups per scan block
 constexpr int kSub = 4;                    // 64-voxel sub-chunks per wavefront chunk (fused kernel)
 constexpr size_t kLdsBytes = 160 * 1024;   // LDS per CU on gfx950
 constexpr size_t kMaxFirstLds = 64 * 1024; // static limit of one workgroup's dynamic LDS without opt-in
 constexpr uint32_t kPersistentBlocks = 256 * 8;   // 256 CUs x 8 workgroups of 4 waves = full occupancy
 constexpr uint32_t kEstimateSamples = 1u << 16;
+constexpr int kEmitBatch = 4;              // survivors per lane in flight together in k_emit_words
 
 }  // namespace
 
@@ -302,7 +303,6 @@ int vc_create(int device, vc_ctx **out)
     hipError_t e1 = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     for (int i = 0; i < 4 && e1 == hipSuccess; ++i) e1 = hipEventCreate(&ctx->ev[i]);
     if (e1 == hipSuccess) e1 = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_total), sizeof(uint64_t), hipHostMallocDefault);
-    if (e1 == hipSuccess) e1 = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_blocksum), sizeof(uint64_t) * kMaxScanBlocks, hipHostMallocDefault);
     if (e1 == hipSuccess) e1 = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_est), sizeof(uint32_t) * VC_MAX_CAMERAS, hipHostMallocDefault);
     const char *fg = getenv("VOXCARVE_FORCE_GENERIC");
     ctx->force_generic = fg && fg[0] == '1';
@@ -323,10 +323,9 @@ int vc_destroy(vc_ctx *ctx)
     if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
     for (Slot &s : ctx->slots) { release(s.bits); release(s.frames); release(s.grid); }
     release(ctx->d_axes); release(ctx->d_stage); release(ctx->d_lut); release(ctx->d_bbox); release(ctx->d_words);
-    release(ctx->d_tilecnt); release(ctx->d_tileoff); release(ctx->d_viewmask);
+    release(ctx->d_groupcnt); release(ctx->d_groupoff); release(ctx->d_blockoff); release(ctx->d_viewmask);
     release(ctx->d_records); release(ctx->d_scratch); release(ctx->d_counts); release(ctx->d_gathered);
     if (ctx->h_total) (void)hipHostFree(ctx->h_total);
-    if (ctx->h_blocksum) (void)hipHostFree(ctx->h_blocksum);
     if (ctx->h_est) (void)hipHostFree(ctx->h_est);
     release(ctx->d_blocksum); release(ctx->d_est);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
@@ -430,7 +429,7 @@ int vc_upload_masks(vc_ctx *ctx, uint32_t slot, const uint8_t *masks)
     VC_TRY(slot_at(ctx, slot, &s));
     VC_HIP(ctx, hipSetDevice(ctx->device));
     const size_t HW = (size_t)ctx->H * ctx->W;
-    VC_TRY(ensure(ctx, ctx->d_stage, HW * ctx->C + 64));
+    VC_TRY(ensure(ctx, ctx->d_stage, HW * (ctx->C > 3 ? ctx->C : 3) + 64));
     VC_TRY(ensure(ctx, s->bits, (size_t)ctx->mwords * ctx->C));
     VC_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     VC_HIP(ctx, hipMemcpyAsync(ctx->d_stage.ptr, masks, HW * ctx->C, hipMemcpyHostToDevice, ctx->stream));
@@ -463,9 +462,13 @@ int vc_upload_frame(vc_ctx *ctx, uint32_t slot, uint32_t cam, const uint8_t *bgr
     VC_TRY(slot_at(ctx, slot, &s));
     if (cam >= ctx->C) return fail(ctx, VC_ERR_ARG, "camera %u not in [0,%u)", cam, ctx->C);
     VC_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t bytes = (size_t)ctx->H * ctx->W * 3;
-    VC_TRY(ensure(ctx, s->frames, bytes * ctx->C));
-    VC_HIP(ctx, hipMemcpyAsync(s->frames.ptr + bytes * cam, bgr, bytes, hipMemcpyHostToDevice, ctx->stream));
+    const size_t npix = (size_t)ctx->H * ctx->W;
+    VC_TRY(ensure(ctx, s->frames, npix * ctx->C));
+    VC_TRY(ensure(ctx, ctx->d_stage, npix * (ctx->C > 3 ? ctx->C : 3) + 64));
+    VC_HIP(ctx, hipMemcpyAsync(ctx->d_stage.ptr, bgr, npix * 3, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_expand_frame, dim3(grid_for(npix)), dim3(kBlock), 0, ctx->stream, ctx->d_stage.ptr,
+                       s->frames.ptr + npix * cam, (uint32_t)npix);
+    VC_HIP(ctx, hipGetLastError());
     VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     s->have_frame[cam] = 1;
     return VC_OK;
@@ -544,12 +547,14 @@ int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int 
     if (n == 0) { ctx->carved = true; ctx->tm.survivors = 0; return VC_OK; }
 
     const uint64_t nwords = (n + 63) / 64;
-    const uint64_t ntiles = (nwords + kWordsPerTile - 1) / kWordsPerTile;
-    const uint32_t nscan = (uint32_t)((ntiles + kScanBlock - 1) / kScanBlock);
-    VC_TRY(ensure(ctx, ctx->d_words, ntiles * kWordsPerTile + kLutPad / 64));
-    VC_TRY(ensure(ctx, ctx->d_tilecnt, ntiles));
-    VC_TRY(ensure(ctx, ctx->d_tileoff, ntiles));
+    const uint64_t n_pad = (n + kLutPad - 1) / kLutPad * kLutPad;
+    const uint32_t ngroups = (uint32_t)(n_pad / (64 * kGroupWords));
+    const uint32_t nscan = (ngroups + kScanBlock - 1) / kScanBlock;
+    VC_TRY(ensure(ctx, ctx->d_words, n_pad / 64));
+    VC_TRY(ensure(ctx, ctx->d_groupcnt, ngroups));
+    VC_TRY(ensure(ctx, ctx->d_groupoff, ngroups));
     VC_TRY(ensure(ctx, ctx->d_blocksum, kMaxScanBlocks));
+    VC_TRY(ensure(ctx, ctx->d_blockoff, kMaxScanBlocks + 1));
     VC_TRY(ensure(ctx, ctx->d_est, VC_MAX_CAMERAS));
     if (want_vm) VC_TRY(ensure(ctx, ctx->d_viewmask, n));
     if (!ctx->d_records.ptr) VC_TRY(ensure(ctx, ctx->d_records, (size_t)(n / 16 + 1024)));
@@ -560,7 +565,7 @@ int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int 
     p.lut = ctx->d_lut.ptr;
     p.blockgrid = s.grid.ptr;
     p.words = ctx->d_words.ptr;
-    p.tilecnt = ctx->d_tilecnt.ptr;
+    p.groupcnt = ctx->d_groupcnt.ptr;
     p.viewmask = ctx->d_viewmask.ptr;
     p.min_views = min_views;
 
@@ -586,7 +591,6 @@ int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int 
     }
     for (uint32_t c = 0; c < ctx->C; ++c) p.order[c] = (fast && ctx->reorder) ? s.order[c] : c;
 
-    VC_HIP(ctx, hipMemsetAsync(ctx->d_tilecnt.ptr, 0, ntiles * sizeof(uint32_t), ctx->stream));
     VC_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     const dim3 block(kBlock);
     if (fast) {
@@ -644,23 +648,33 @@ int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int 
     VC_HIP(ctx, hipGetLastError());
     VC_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
 
-    hipLaunchKernelGGL(k_scan_tiles, dim3(nscan), dim3(kScanBlock), 0, ctx->stream, ctx->d_tilecnt.ptr, ntiles,
-                       ctx->d_tileoff.ptr, ctx->d_blocksum.ptr);
+    // kernels that do not know their group totals (fused, generic, the padded tail) get them counted
+    const bool counted = fast && mode == VC_MODE_LUT;
+    if (!counted) {
+        hipLaunchKernelGGL(k_count_groups, dim3((ngroups + 3) / 4), block, 0, ctx->stream, ctx->d_words.ptr, nwords,
+                           ngroups, ctx->d_groupcnt.ptr);
+        VC_HIP(ctx, hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_scan_groups, dim3(nscan), dim3(kScanBlock), 0, ctx->stream, ctx->d_groupcnt.ptr, ngroups,
+                       ctx->d_groupoff.ptr, ctx->d_blocksum.ptr);
     VC_HIP(ctx, hipGetLastError());
-    VC_HIP(ctx, hipMemcpyAsync(ctx->h_blocksum, ctx->d_blocksum.ptr, sizeof(uint64_t) * nscan, hipMemcpyDeviceToHost, ctx->stream));
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(kScanBlock), 0, ctx->stream, ctx->d_blocksum.ptr, nscan,
+                       ctx->d_blockoff.ptr);
+    VC_HIP(ctx, hipGetLastError());
+    VC_HIP(ctx, hipMemcpyAsync(ctx->h_total, ctx->d_blockoff.ptr + nscan, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
 
     EmitParams e;
     memset(&e, 0, sizeof e);
     e.xs = p.xs; e.ys = p.ys; e.zs = p.zs;
-    e.words = ctx->d_words.ptr; e.tilecnt = ctx->d_tilecnt.ptr; e.tileoff = ctx->d_tileoff.ptr;
-    e.blocksum = ctx->d_blocksum.ptr;
-    e.n = n; e.i0 = ctx->i0(); e.nx = ctx->nx; e.ny = ctx->ny; e.z0 = ctx->z0; e.H = ctx->H; e.W = ctx->W;
+    e.words = ctx->d_words.ptr; e.groupcnt = ctx->d_groupcnt.ptr; e.groupoff = ctx->d_groupoff.ptr; e.blockoff = ctx->d_blockoff.ptr;
+    e.n = n; e.i0 = ctx->i0(); e.ngroups = ngroups;
+    e.nx = ctx->nx; e.ny = ctx->ny; e.z0 = ctx->z0; e.H = ctx->H; e.W = ctx->W;
     if (color_cam >= 0) {
         e.has_cam = 1;
         e.cam = ctx->cams[color_cam];
         e.maskbits = s.bits.ptr + (size_t)color_cam * ctx->mwords;
         if (s.frames.ptr && s.have_frame[color_cam])
-            e.frame = s.frames.ptr + (size_t)color_cam * ctx->H * ctx->W * 3;
+            e.frame = s.frames.ptr + (size_t)color_cam * ctx->H * ctx->W;
         if (mode == VC_MODE_LUT) e.lut = ctx->d_lut.ptr + (size_t)color_cam * p.n_pad;
     }
     uint64_t total = 0;
@@ -668,19 +682,17 @@ int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int 
         e.records = ctx->d_records.ptr;
         e.capacity = ctx->d_records.cap;
         {
-            const dim3 eg((uint32_t)ntiles), eb(kEmitBlock);
-            const uint32_t nt = (uint32_t)ntiles;
+            const dim3 eg((ngroups + 3) / 4);
             const bool allseen = min_views >= ctx->C;
-            if (e.lut && allseen) hipLaunchKernelGGL((k_emit<true, true>), eg, eb, 0, ctx->stream, e, nt);
-            else if (e.lut) hipLaunchKernelGGL((k_emit<true, false>), eg, eb, 0, ctx->stream, e, nt);
-            else if (allseen) hipLaunchKernelGGL((k_emit<false, true>), eg, eb, 0, ctx->stream, e, nt);
-            else hipLaunchKernelGGL((k_emit<false, false>), eg, eb, 0, ctx->stream, e, nt);
+            if (e.lut && allseen) hipLaunchKernelGGL((k_emit_words<true, true, kEmitBatch>), eg, block, 0, ctx->stream, e);
+            else if (e.lut) hipLaunchKernelGGL((k_emit_words<true, false, kEmitBatch>), eg, block, 0, ctx->stream, e);
+            else if (allseen) hipLaunchKernelGGL((k_emit_words<false, true, kEmitBatch>), eg, block, 0, ctx->stream, e);
+            else hipLaunchKernelGGL((k_emit_words<false, false, kEmitBatch>), eg, block, 0, ctx->stream, e);
         }
         VC_HIP(ctx, hipGetLastError());
         VC_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
         VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        total = 0;
-        for (uint32_t b = 0; b < nscan; ++b) total += ctx->h_blocksum[b];
+        total = *ctx->h_total;
         if (total <= ctx->d_records.cap) break;
         if (attempt == 1) return fail(ctx, VC_ERR_HIP, "survivor buffer still too small after regrow");
         VC_TRY(ensure(ctx, ctx->d_records, (size_t)(total + total / 8 + 1024)));
