@@ -9,9 +9,7 @@ frames = fx.synthetic_frames(4, *masks[0].shape)
 eng = voxcarve.CarveEngine(0)
 eng.set_grid(1024, 1024, 1024); eng.set_cameras(cams, *masks[0].shape)
 eng.upload_masks(masks); eng.build_lut()
-for label, cc, frame, dbg in (("no colour camera", None, False, 0), ("no colour, no store", None, False, 1), ("no colour, no search", None, False, 2),
-                              ("no colour, no store no search", None, False, 3), ("colour cam + frame", 1, True, 0)):
-    eng.set_option("emit_debug", dbg)
+for label, cc, frame in (("no colour camera", None, False), ("colour cam, no frame uploaded", 1, False), ("colour cam + frame", 1, True)):
     if frame:
         eng.upload_frame(1, frames[1])
     ts = []
