@@ -139,6 +139,38 @@ def test_random_scenes_ragged_shapes(eng, seed):
                     assert np.array_equal(eng.fetch_viewmask(), want["viewmask"])
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_every_kernel_family_agrees_with_oracle(eng, seed):
+    """The same scene through each carve implementation: hierarchical LUT (default), streaming LUT
+    (k_lut_first + k_lut_refine), chunked fused, and the one-thread-per-voxel kernels."""
+    from oracle import carve_c
+    cams3, masks3, frames3 = fx.random_scene(100 + seed, C=4, H=60 + 7 * seed, W=80, fg=0.55)
+    grid = [(16, 128, 24), (40, 64, 9), (8, 192, 33), (5, 70, 19)][seed]        # last: ny % 64 != 0
+    want = carve_c.carve(*grid, fx.oracle_cams(cams3), masks3, frames3, color_cam=2)
+    assert want["count"] > 0
+    eng.set_grid(*grid)
+    eng.set_cameras(cams3, *masks3[0].shape)
+    eng.upload_masks(masks3)
+    eng.upload_frame(2, frames3[2])
+    eng.build_lut()
+    try:
+        for opts in ({"lut_hier": 1}, {"lut_hier": 0}, {"lut_hier": 0, "first_kv": 4}, {"lut_hier": 1, "refine_b": 16, "refine_wl": 2},
+                     {"reorder": 0}, {"force_generic": 1}):
+            for k, v in opts.items():
+                eng.set_option(k, v)
+            for mode in ("lut", "fused"):
+                assert eng.carve(mode=mode, color_cam=2) == want["count"], (opts, mode)
+                idx, rgb, seen = eng.fetch()
+                assert np.array_equal(idx, want["idx"]) and np.array_equal(rgb[:, ::-1], want["bgr"]) and seen.all(), (opts, mode)
+            for k in opts:
+                eng.set_option(k, {"lut_hier": 1, "first_kv": 1, "refine_b": 8, "refine_wl": 1, "reorder": 1, "force_generic": 0}[k])
+    finally:
+        for k, v in {"lut_hier": 1, "first_kv": 1, "refine_b": 8, "refine_wl": 1, "reorder": 1, "force_generic": 0}.items():
+            eng.set_option(k, v)
+    with pytest.raises(Exception):
+        eng.set_option("no_such_option", 1)
+
+
 def test_config5_shape_16_cameras_1080p(eng):
     """BASELINE config 5 inputs (16 synthetic ring cameras, 1080x1920 masks, colour on) at an
     oracle-sized grid: masks too large for the LDS path, 16-bit camera bitmask, all modes."""
