@@ -466,6 +466,129 @@ __global__ __launch_bounds__(kBlock) void k_carve_fused(const CarveParams p)
     }
 }
 
+// ---------------------------------------------------------------- fused carve, hierarchical
+// Table-free counterpart of the hierarchical LUT carve (needs ny % 64 == 0, so a word is 64
+// consecutive y of one (x, z) column).  Coarse pass, lane = word: the camera-frame coordinates
+// are linear in y, so the word is a line segment; interval arithmetic through OpenCV's projection
+// (division, distortion polynomial, intrinsics) gives a pixel box that CONTAINS every voxel's
+// pixel.  The box is widened by a pixel and a relative 1e-9, orders of magnitude above the
+// float64 rounding of the interval evaluation, and a word whose interval cannot be bounded
+// (depth interval touching zero, non-finite values) is simply kept.  A word survives the coarse
+// pass only if every camera's box holds a foreground block (LDS grid).  Fine pass: the exact
+// per-voxel float64 test of k_carve_fused, for the candidate words only.
+struct Iv { double lo, hi; };
+
+__device__ __forceinline__ Iv iv_add(Iv a, Iv b) { return {a.lo + b.lo, a.hi + b.hi}; }
+__device__ __forceinline__ Iv iv_addc(Iv a, double c) { return {a.lo + c, a.hi + c}; }
+__device__ __forceinline__ Iv iv_scale(Iv a, double k) { return k >= 0 ? Iv{a.lo * k, a.hi * k} : Iv{a.hi * k, a.lo * k}; }
+__device__ __forceinline__ Iv iv_mul(Iv a, Iv b)
+{
+    const double p0 = a.lo * b.lo, p1 = a.lo * b.hi, p2 = a.hi * b.lo, p3 = a.hi * b.hi;
+    return {fmin(fmin(p0, p1), fmin(p2, p3)), fmax(fmax(p0, p1), fmax(p2, p3))};
+}
+__device__ __forceinline__ Iv iv_sqr(Iv a)
+{
+    const double l = a.lo * a.lo, h = a.hi * a.hi;
+    if (a.lo <= 0.0 && a.hi >= 0.0) return {0.0, fmax(l, h)};
+    return {fmin(l, h), fmax(l, h)};
+}
+
+// Pixel box of the segment {(X, y, Z): y in [ya, yb]} for camera c, packed as bbox words are;
+// kEmptyBox when no voxel of it can be inside the image; ~1ull ("maybe") when it cannot be bounded.
+constexpr uint64_t kMaybeBox = ~1ull;
+__device__ __forceinline__ uint64_t segment_box(const CamDev &c, double X, double ya, double yb, double Z,
+                                                uint32_t H, uint32_t W)
+{
+    const Iv Y = {fmin(ya, yb), fmax(ya, yb)};
+    const Iv x = iv_addc(iv_scale(Y, c.r[1]), c.r[0] * X + c.r[2] * Z + c.t[0]);
+    const Iv y = iv_addc(iv_scale(Y, c.r[4]), c.r[3] * X + c.r[5] * Z + c.t[1]);
+    const Iv z = iv_addc(iv_scale(Y, c.r[7]), c.r[6] * X + c.r[8] * Z + c.t[2]);
+    // keep a margin around z = 0: there the projection takes the `z ? 1/z : 1` branch or blows up
+    const double zmag = fmax(fabs(z.lo), fabs(z.hi));
+    if (!(z.lo > 1e-6 * zmag || z.hi < -1e-6 * zmag) || zmag == 0.0) return kMaybeBox;
+    const Iv inv = {1.0 / z.hi, 1.0 / z.lo};
+    const Iv xn = iv_mul(x, inv), yn = iv_mul(y, inv);
+    const Iv x2 = iv_sqr(xn), y2 = iv_sqr(yn);
+    const Iv r2 = iv_add(x2, y2);
+    const Iv r4 = iv_sqr(r2);
+    const Iv r6 = iv_mul(r4, r2);
+    const Iv cdist = iv_addc(iv_add(iv_add(iv_scale(r2, c.k1), iv_scale(r4, c.k2)), iv_scale(r6, c.k3)), 1.0);
+    const Iv a1 = iv_scale(iv_mul(xn, yn), 2.0);
+    const Iv a2 = iv_add(r2, iv_scale(x2, 2.0));
+    const Iv a3 = iv_add(r2, iv_scale(y2, 2.0));
+    const Iv xd = iv_add(iv_add(iv_mul(xn, cdist), iv_scale(a1, c.p1)), iv_scale(a2, c.p2));
+    const Iv yd = iv_add(iv_add(iv_mul(yn, cdist), iv_scale(a3, c.p1)), iv_scale(a1, c.p2));
+    Iv u = iv_addc(iv_scale(xd, c.fx), c.cx);
+    Iv v = iv_addc(iv_scale(yd, c.fy), c.cy);
+    if (!(isfinite(u.lo) && isfinite(u.hi) && isfinite(v.lo) && isfinite(v.hi))) return kMaybeBox;
+    u.lo -= 1.0 + 1e-9 * fabs(u.lo); u.hi += 1.0 + 1e-9 * fabs(u.hi);
+    v.lo -= 1.0 + 1e-9 * fabs(v.lo); v.hi += 1.0 + 1e-9 * fabs(v.hi);
+    if (u.hi < 0.0 || v.hi < 0.0 || u.lo >= (double)W || v.lo >= (double)H) return kEmptyBox;
+    const uint32_t u0 = u.lo > 0.0 ? (uint32_t)u.lo : 0u, v0 = v.lo > 0.0 ? (uint32_t)v.lo : 0u;
+    const uint32_t u1 = u.hi < (double)(W - 1) ? (uint32_t)u.hi : W - 1, v1 = v.hi < (double)(H - 1) ? (uint32_t)v.hi : H - 1;
+    return (uint64_t)u0 | ((uint64_t)v0 << 16) | ((uint64_t)u1 << 32) | ((uint64_t)v1 << 48);
+}
+
+__global__ __launch_bounds__(kBlock) void k_carve_fused_hier(const CarveParams p)
+{
+    extern __shared__ uint32_t s_grid[];                          // [C][gh][gws]
+    {
+        const uint32_t total = p.C * p.gh * p.gws;
+        for (uint32_t i = threadIdx.x; i < total; i += kBlock) s_grid[i] = p.blockgrid[i];
+        __syncthreads();
+    }
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
+    const uint32_t nwaves = gridDim.x * (kBlock / 64);
+    const uint32_t ngroups = (uint32_t)(p.n_pad / 4096);
+    for (uint32_t g = wave0; g < ngroups; g += nwaves) {
+        const uint64_t gw = (uint64_t)g * 64;
+        // ---- coarse: lane = word
+        const uint64_t j0 = (gw + lane) << 6;
+        bool cand = j0 < p.n;                                     // n % 64 == 0 here: whole words only
+        uint32_t ix = 0, iy = 0, izl = 0;
+        if (cand) decompose((uint32_t)j0, p.nx, p.ny, ix, iy, izl);
+        const double X = p.xs[ix], Z = p.zs[p.z0 + izl];
+        const double ya = p.ys[iy], yb = p.ys[iy + 63 < p.ny ? iy + 63 : p.ny - 1];
+        for (uint32_t q = 0; q < p.C && __ballot(cand) != 0; ++q) {
+            const uint32_t c = p.order[q];
+            if (cand) {
+                const uint64_t bb = segment_box(p.cam[c], X, ya, yb, Z, p.H, p.W);
+                if (bb != kMaybeBox) cand = box_may_hit(s_grid + (size_t)c * p.gh * p.gws, bb, p.gshift, p.gws);
+            }
+        }
+        // ---- fine: lanes = the 64 voxels of one candidate word, exact float64 test
+        uint64_t nz = __ballot(cand);
+        uint64_t mine = 0;
+        while (nz != 0) {                                         // wave-uniform
+            const uint32_t l = (uint32_t)__builtin_ctzll(nz);
+            nz &= nz - 1;
+            const uint32_t wix = (uint32_t)__builtin_amdgcn_readlane((int)ix, (int)l);
+            const uint32_t wiy = (uint32_t)__builtin_amdgcn_readlane((int)iy, (int)l);
+            const uint32_t wiz = (uint32_t)__builtin_amdgcn_readlane((int)izl, (int)l);
+            const double VX = p.xs[wix], VY = p.ys[wiy + lane], VZ = p.zs[p.z0 + wiz];
+            bool alive = true;
+            for (uint32_t q = 0; q < p.C; ++q) {
+                const uint32_t c = p.order[q];
+                if (alive) {
+                    double u, v;
+                    project_point(p.cam[c], VX, VY, VZ, u, v);
+                    const int32_t off = pixel_offset(u, v, p.H, p.W);
+                    alive = off >= 0 && mask_bit(p.maskbits + (size_t)c * p.mwords, off);
+                }
+                if (__ballot(alive) == 0) break;
+            }
+            const uint64_t nb = __ballot(alive);
+            if (lane == l) mine = nb;
+        }
+        p.words[gw + lane] = mine;
+        uint32_t cnt = (uint32_t)__popcll(mine);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
+        if (lane == 0) p.groupcnt[g] = cnt;
+    }
+}
+
 // ---------------------------------------------------------------- LUT build
 // create_lookup_table: every camera, every voxel of the slab.  Also reduces, per camera and
 // 64-voxel word, the bounding box of the pixels its in-image voxels land on (u16 x 4); the

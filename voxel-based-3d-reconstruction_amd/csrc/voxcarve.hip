@@ -155,6 +155,7 @@ struct vc_ctx {
     int reorder = 1;                 // visit the most selective camera first
     int refine_wl = 1;               // words per lane in the hierarchical kernel's groups: 1 or 2
     int hier_blocks_per_cu = 48;     // hierarchical kernel: oversubscribed grid, the dispatcher balances uneven groups
+    int fused_hier = 1;              // VC_MODE_FUSED: interval-arithmetic word rejection (needs ny % 64 == 0)
     int lut_hier = 1;                // VC_MODE_LUT: hierarchical kernel (boxes + block grid) instead of stream + refine
     DevBuf<uint16_t> d_viewmask;
     DevBuf<uint64_t> d_records;
@@ -633,6 +634,14 @@ int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int 
             if (ctx->refine_b == 8) hipLaunchKernelGGL((k_lut_refine<8, false, 1>), rgrid, block, 0, ctx->stream, p);
             else hipLaunchKernelGGL((k_lut_refine<16, false, 1>), rgrid, block, 0, ctx->stream, p);
         }
+        else if (ctx->ny % 64 == 0 && ctx->fused_hier) {
+            const size_t lds = (size_t)ctx->C * ctx->gh * ctx->gws * sizeof(uint32_t);
+            const uint64_t groups = p.n_pad / 4096;
+            const uint64_t rwant = (groups + 3) / 4;
+            const uint64_t rmax = 256ull * 2 * (uint64_t)ctx->hier_blocks_per_cu;      // more, shorter workgroups: 96/CU measured best
+            const dim3 rgrid((uint32_t)(rwant < rmax ? rwant : rmax));
+            hipLaunchKernelGGL(k_carve_fused_hier, rgrid, block, lds, ctx->stream, p);
+        }
         else if (ctx->ny % 64 == 0) hipLaunchKernelGGL((k_carve_fused<kSub, true>), grid, block, 0, ctx->stream, p);
         else hipLaunchKernelGGL((k_carve_fused<kSub, false>), grid, block, 0, ctx->stream, p);
     } else {
@@ -649,7 +658,7 @@ int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int 
     VC_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
 
     // kernels that do not know their group totals (fused, generic, the padded tail) get them counted
-    const bool counted = fast && mode == VC_MODE_LUT;
+    const bool counted = fast && (mode == VC_MODE_LUT || (ctx->ny % 64 == 0 && ctx->fused_hier));
     if (!counted) {
         hipLaunchKernelGGL(k_count_groups, dim3((ngroups + 3) / 4), block, 0, ctx->stream, ctx->d_words.ptr, nwords,
                            ngroups, ctx->d_groupcnt.ptr);
@@ -787,6 +796,7 @@ int vc_set_option(vc_ctx *ctx, const char *name, int value)
     if (k == "force_generic") ctx->force_generic = value != 0;
     else if (k == "reorder") ctx->reorder = value != 0;
     else if (k == "lut_hier") ctx->lut_hier = value != 0;
+    else if (k == "fused_hier") ctx->fused_hier = value != 0;
     else if (k == "refine_wl" && (value == 1 || value == 2)) ctx->refine_wl = value;
     else if (k == "hier_blocks_per_cu" && value >= 1 && value <= 4096) ctx->hier_blocks_per_cu = value;
     else if (k == "first_kv" && (value == 1 || value == 2 || value == 4)) ctx->first_kv = value;
