@@ -17,8 +17,8 @@ same input; synthetic colour frames.
 
 Prints ONE JSON line on rank 0.  `value` is the headline mode (default lut: the table-
 streaming form the reference's per-call function has, HBM-bound); the other mode is timed
-too and reported under "other_mode".  torch is imported only for the N > 1 rendezvous
-(gloo barrier / max-reduce); the data path is libvoxcarve + RCCL.
+too and reported under "other_modes".  No framework is imported: for N > 1 the RCCL unique id
+travels through a node-local file and barriers / the max-over-ranks timing go through RCCL.
 """
 import argparse
 import json
@@ -59,9 +59,13 @@ def parse():
 
 
 class Group:
-    """Rank bookkeeping; torch.distributed (gloo) only when world > 1."""
+    """Rank bookkeeping.  N > 1: the RCCL unique id travels through a node-local file, and barriers /
+    max-reductions go through RCCL itself (vc_comm_allreduce_max) once the communicator exists -- no
+    framework import: torch wheels bundle their own ROCm runtime, and a process holding two of them
+    breaks RCCL's HSA lookup (found on the GPU box).  `--transport host` (rehearsal on one GPU) is the
+    only path that imports torch.distributed (gloo)."""
 
-    def __init__(self, n_gpus):
+    def __init__(self, n_gpus, use_torch=False):
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -71,38 +75,32 @@ class Group:
                                  "python -m torch.distributed.run --nproc-per-node %d bench.py ..." % (n_gpus, n_gpus))
             raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (self.world, n_gpus))
         self.dist = None
-        if self.world > 1:
+        self.eng = None
+        if self.world > 1 and use_torch:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             import torch.distributed as dist
             dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
             self.dist = dist
 
+    def attach(self, eng):
+        """From here on barriers and reductions run over the engine's RCCL communicator."""
+        self.eng = eng
+
     def barrier(self):
         if self.dist:
             self.dist.barrier()
-
-    def bcast_bytes(self, payload):
-        if not self.dist:
-            return payload
-        box = [payload]
-        self.dist.broadcast_object_list(box, src=0)
-        return box[0]
+        elif self.eng is not None and self.world > 1:
+            self.eng.comm_max(0.0)
 
     def max(self, x):
-        if not self.dist:
-            return x
-        import torch
-        t = torch.tensor([x], dtype=torch.float64)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t.item())
-
-    def sum(self, x):
-        if not self.dist:
-            return x
-        import torch
-        t = torch.tensor([x], dtype=torch.float64)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return float(t.item())
+        if self.dist:
+            import torch
+            t = torch.tensor([x], dtype=torch.float64)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            return float(t.item())
+        if self.eng is not None and self.world > 1:
+            return self.eng.comm_max(x)
+        return x
 
     def close(self):
         if self.dist:
@@ -171,7 +169,7 @@ def main():
     args = parse()
     import voxcarve
     voxcarve._lib.load()                 # libvoxcarve (system HIP runtime) is loaded before any torch import
-    grp = Group(args.gpus)
+    grp = Group(args.gpus, use_torch=(args.transport == "host"))
     import fixtures_util as fx
     from voxcarve import slabs
 
@@ -195,8 +193,11 @@ def main():
     if multi and args.transport == "host":
         host_transport = slabs.TorchTransport()
     elif multi:
-        uid = grp.bcast_bytes(voxcarve.CarveEngine.comm_unique_id() if grp.rank == 0 else None)
+        uid = slabs.file_rendezvous(grp.rank, voxcarve.CarveEngine.comm_unique_id() if grp.rank == 0 else None)
         eng.comm_init(grp.world, grp.rank, uid)
+        grp.attach(eng)
+        grp.barrier()
+        slabs.file_rendezvous_cleanup(grp.rank)
     eng.build_lut()
     lut_ms = eng.timing()["lut_ms"]
 

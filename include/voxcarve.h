@@ -136,6 +136,8 @@ int vc_comm_destroy(vc_ctx *ctx);
  * counts_out (NULL ok): n_ranks entries.  *total_out = global survivor count. */
 int vc_allgather(vc_ctx *ctx, uint64_t *counts_out, uint64_t *total_out);
 int vc_fetch_gathered(vc_ctx *ctx, uint64_t *records);
+/* Max of one double over all ranks via RCCL (doubles as a barrier for host code). */
+int vc_comm_allreduce_max(vc_ctx *ctx, double *inout);
 
 #ifdef __cplusplus
 }

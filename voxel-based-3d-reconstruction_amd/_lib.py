@@ -70,6 +70,7 @@ SIGNATURES = {
     "vc_comm_destroy": (ctypes.c_int, [c_ctx]),
     "vc_allgather": (ctypes.c_int, [c_ctx, c_u64p, c_u64p]),
     "vc_fetch_gathered": (ctypes.c_int, [c_ctx, c_u64p]),
+    "vc_comm_allreduce_max": (ctypes.c_int, [c_ctx, c_f64p]),
 }
 
 _lib = None

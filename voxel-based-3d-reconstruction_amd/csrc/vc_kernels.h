@@ -274,7 +274,7 @@ __device__ __forceinline__ bool box_may_hit(const uint32_t *__restrict__ g, uint
 //               the block grid (LDS) has foreground inside the word's pixel box; candidates
 //               then take the exact per-voxel test through all cameras.  Exact: a box with no
 //               foreground block cannot contain a foreground pixel of any of its voxels.
-template <int B, bool HIER, int WL>
+template <int B, bool HIER, int WL, bool PAIR>
 __global__ __launch_bounds__(kBlock) void k_lut_refine(const CarveParams p)
 {
     extern __shared__ uint32_t s_grid[];                          // HIER: [C][gh][gws]
@@ -359,19 +359,29 @@ __global__ __launch_bounds__(kBlock) void k_lut_refine(const CarveParams p)
                     }
                 }
             }
-            for (uint32_t q = qfirst; q < p.C; ++q) {
-                const uint32_t c = p.order[q];
+            for (uint32_t q = qfirst; q < p.C; q += PAIR ? 2 : 1) {
+                // PAIR: two cameras' entries per dependent round trip (their loads and gathers overlap)
+                const bool two = PAIR && q + 1 < p.C;
+                const uint32_t c = p.order[q], c2 = p.order[two ? q + 1 : q];
                 const int32_t *__restrict__ L = p.lut + (size_t)c * p.n_pad + gw * 64 + lane;
+                const int32_t *__restrict__ L2 = p.lut + (size_t)c2 * p.n_pad + gw * 64 + lane;
                 const uint32_t *__restrict__ mb = p.maskbits + (size_t)c * p.mwords;
-                int32_t off[B];
-                uint32_t mw[B];
+                const uint32_t *__restrict__ mb2 = p.maskbits + (size_t)c2 * p.mwords;
+                int32_t off[B], off2[B];
+                uint32_t mw[B], mw2[B];
 #pragma unroll
-                for (int b = 0; b < B; ++b) off[b] = ((alive >> b) & 1u) ? L[(size_t)li[b] * 64] : -1;
+                for (int b = 0; b < B; ++b) {
+                    off[b] = ((alive >> b) & 1u) ? L[(size_t)li[b] * 64] : -1;
+                    off2[b] = (two && ((alive >> b) & 1u)) ? L2[(size_t)li[b] * 64] : (two ? -1 : 0);
+                }
 #pragma unroll
-                for (int b = 0; b < B; ++b) mw[b] = (off[b] >= 0) ? mb[(uint32_t)off[b] >> 5] : 0u;
+                for (int b = 0; b < B; ++b) {
+                    mw[b] = (off[b] >= 0) ? mb[(uint32_t)off[b] >> 5] : 0u;
+                    mw2[b] = (two && off2[b] >= 0) ? mb2[(uint32_t)off2[b] >> 5] : (two ? 0u : ~0u);
+                }
 #pragma unroll
                 for (int b = 0; b < B; ++b)
-                    if (!((mw[b] >> ((uint32_t)off[b] & 31u)) & 1u)) alive &= ~(1u << b);
+                    if (!((mw[b] >> ((uint32_t)off[b] & 31u)) & (mw2[b] >> ((uint32_t)off2[b] & 31u)) & 1u)) alive &= ~(1u << b);
                 if (__ballot(alive != 0) == 0) break;
             }
 #pragma unroll

@@ -45,6 +45,7 @@ struct RcclApi {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
@@ -69,6 +70,7 @@ bool load_rccl(std::string &err)
     VC_SYM(CommDestroy, "ncclCommDestroy")
     VC_SYM(AllGather, "ncclAllGather")
     VC_SYM(Broadcast, "ncclBroadcast")
+    VC_SYM(AllReduce, "ncclAllReduce")
     VC_SYM(GroupStart, "ncclGroupStart")
     VC_SYM(GroupEnd, "ncclGroupEnd")
     VC_SYM(GetErrorString, "ncclGetErrorString")
@@ -155,6 +157,7 @@ struct vc_ctx {
     int reorder = 1;                 // visit the most selective camera first
     int refine_wl = 1;               // words per lane in the hierarchical kernel's groups: 1 or 2
     int hier_blocks_per_cu = 48;     // hierarchical kernel: oversubscribed grid, the dispatcher balances uneven groups
+    int refine_pair = 1;             // hierarchical LUT kernel: two cameras per dependent round trip
     int fused_hier = 1;              // VC_MODE_FUSED: interval-arithmetic word rejection (needs ny % 64 == 0)
     int lut_hier = 1;                // VC_MODE_LUT: hierarchical kernel (boxes + block grid) instead of stream + refine
     DevBuf<uint16_t> d_viewmask;
@@ -607,10 +610,11 @@ int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int 
             const uint64_t rwant = (groups + 3) / 4;
             const uint64_t rmax = 256ull * (uint64_t)ctx->hier_blocks_per_cu;
             const dim3 rgrid((uint32_t)(rwant < rmax ? rwant : rmax));
-            if (ctx->refine_b == 8 && wl == 1) hipLaunchKernelGGL((k_lut_refine<8, true, 1>), rgrid, block, lds, ctx->stream, p);
-            else if (ctx->refine_b == 8) hipLaunchKernelGGL((k_lut_refine<8, true, 2>), rgrid, block, lds, ctx->stream, p);
-            else if (wl == 1) hipLaunchKernelGGL((k_lut_refine<16, true, 1>), rgrid, block, lds, ctx->stream, p);
-            else hipLaunchKernelGGL((k_lut_refine<16, true, 2>), rgrid, block, lds, ctx->stream, p);
+            if (ctx->refine_pair) hipLaunchKernelGGL((k_lut_refine<8, true, 1, true>), rgrid, block, lds, ctx->stream, p);
+            else if (ctx->refine_b == 8 && wl == 1) hipLaunchKernelGGL((k_lut_refine<8, true, 1, false>), rgrid, block, lds, ctx->stream, p);
+            else if (ctx->refine_b == 8) hipLaunchKernelGGL((k_lut_refine<8, true, 2, false>), rgrid, block, lds, ctx->stream, p);
+            else if (wl == 1) hipLaunchKernelGGL((k_lut_refine<16, true, 1, false>), rgrid, block, lds, ctx->stream, p);
+            else hipLaunchKernelGGL((k_lut_refine<16, true, 2, false>), rgrid, block, lds, ctx->stream, p);
             VC_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
         } else if (mode == VC_MODE_LUT) {
             const size_t lds = (size_t)ctx->mwords * sizeof(uint32_t);
@@ -631,8 +635,8 @@ int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int 
             const uint64_t rwant = (groups + 3) / 4;
             const uint64_t rmax = 256ull * (uint64_t)ctx->refine_blocks_per_cu;
             const dim3 rgrid((uint32_t)(rwant < rmax ? rwant : rmax));
-            if (ctx->refine_b == 8) hipLaunchKernelGGL((k_lut_refine<8, false, 1>), rgrid, block, 0, ctx->stream, p);
-            else hipLaunchKernelGGL((k_lut_refine<16, false, 1>), rgrid, block, 0, ctx->stream, p);
+            if (ctx->refine_b == 8) hipLaunchKernelGGL((k_lut_refine<8, false, 1, false>), rgrid, block, 0, ctx->stream, p);
+            else hipLaunchKernelGGL((k_lut_refine<16, false, 1, false>), rgrid, block, 0, ctx->stream, p);
         }
         else if (ctx->ny % 64 == 0 && ctx->fused_hier) {
             const size_t lds = (size_t)ctx->C * ctx->gh * ctx->gws * sizeof(uint32_t);
@@ -797,6 +801,7 @@ int vc_set_option(vc_ctx *ctx, const char *name, int value)
     else if (k == "reorder") ctx->reorder = value != 0;
     else if (k == "lut_hier") ctx->lut_hier = value != 0;
     else if (k == "fused_hier") ctx->fused_hier = value != 0;
+    else if (k == "refine_pair") ctx->refine_pair = value != 0;
     else if (k == "refine_wl" && (value == 1 || value == 2)) ctx->refine_wl = value;
     else if (k == "hier_blocks_per_cu" && value >= 1 && value <= 4096) ctx->hier_blocks_per_cu = value;
     else if (k == "first_kv" && (value == 1 || value == 2 || value == 4)) ctx->first_kv = value;
@@ -911,6 +916,22 @@ int vc_allgather(vc_ctx *ctx, uint64_t *counts_out, uint64_t *total_out)
     ctx->gathered_total = total;
     ctx->gathered = true;
     *total_out = total;
+    return VC_OK;
+}
+
+// Max over ranks of one double, through the device (RCCL all-reduce): a barrier and a timing
+// reduction for host code that must not load a second ROCm runtime.
+int vc_comm_allreduce_max(vc_ctx *ctx, double *inout)
+{
+    if (!ctx || !inout) return VC_ERR_ARG;
+    if (!ctx->comm) return fail(ctx, VC_ERR_ARG, "vc_comm_init must precede vc_comm_allreduce_max");
+    VC_HIP(ctx, hipSetDevice(ctx->device));
+    VC_TRY(ensure(ctx, ctx->d_scratch, 16));
+    double *d = ctx->d_scratch.ptr;
+    VC_HIP(ctx, hipMemcpyAsync(d, inout, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    VC_NCCL(ctx, g_rccl.AllReduce(d, d + 1, 1, ncclFloat64, ncclMax, ctx->comm, ctx->stream));
+    VC_HIP(ctx, hipMemcpyAsync(inout, d + 1, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return VC_OK;
 }
 

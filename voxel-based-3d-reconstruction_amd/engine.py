@@ -209,6 +209,15 @@ class CarveEngine:
         return bytes(buf)
 
     def comm_init(self, n_ranks, rank, uid):
+        import os
+        import sys
+        if "torch" in sys.modules and os.environ.get("VOXCARVE_ALLOW_TORCH") != "1":
+            # Measured on the GPU box: a torch wheel bundles its own libhsa-runtime64 / librccl; once it is
+            # loaded, RCCL resolves HSA from that uninitialised copy and ncclCommInitRank fails with
+            # "no ROCm-capable device is detected".  Exchange the unique id without a framework
+            # (slabs.file_rendezvous) or set VOXCARVE_ALLOW_TORCH=1 if your torch uses the system ROCm.
+            raise _lib.VoxcarveError("comm_init in a process that imported torch: its bundled ROCm runtime breaks RCCL "
+                                     "(see voxcarve.slabs.file_rendezvous); set VOXCARVE_ALLOW_TORCH=1 to try anyway")
         buf = (ctypes.c_uint8 * _lib.VC_UNIQUE_ID_BYTES).from_buffer_copy(uid)
         self._check(self._L.vc_comm_init(self._ctx, n_ranks, rank, buf), "vc_comm_init")
         self.n_ranks, self.rank = n_ranks, rank
@@ -224,6 +233,12 @@ class CarveEngine:
                     "vc_allgather")
         self.gathered_total = int(total.value)
         return counts, self.gathered_total
+
+    def comm_max(self, value=0.0):
+        """Max of `value` over all ranks through RCCL; with the default it is a barrier."""
+        v = ctypes.c_double(float(value))
+        self._check(self._L.vc_comm_allreduce_max(self._ctx, ctypes.byref(v)), "vc_comm_allreduce_max")
+        return v.value
 
     def fetch_gathered(self):
         rec = np.empty(self.gathered_total, dtype=np.uint64)

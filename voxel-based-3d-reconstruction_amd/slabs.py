@@ -84,6 +84,44 @@ class TorchTransport:
         return self._gathered
 
 
+def file_rendezvous(rank, payload=None, tag="uid", timeout=120.0):
+    """One-shot broadcast from rank 0 through the node-local filesystem (one process per GPU on ONE
+    node).  Used to hand the RCCL unique id to the other ranks without importing a framework: a
+    process that uses vc_comm_* must not load a second ROCm runtime (torch wheels bundle their own
+    libhsa / librccl, and RCCL then resolves HSA from the wrong copy).  The directory is keyed by the
+    launcher's PID (identical for all ranks of one launch, unique per launch) and MASTER_PORT."""
+    import os
+    import time
+    d = os.path.join("/tmp", "voxcarve_rdzv_%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0")))
+    path = os.path.join(d, tag)
+    if rank == 0:
+        os.makedirs(d, exist_ok=True)
+        tmp = path + ".tmp"
+        with open(tmp, "wb") as f:
+            f.write(payload)
+        os.replace(tmp, path)
+        return payload
+    t_end = time.time() + timeout
+    while time.time() < t_end:
+        try:
+            with open(path, "rb") as f:
+                data = f.read()
+            if data:
+                return data
+        except FileNotFoundError:
+            pass
+        time.sleep(0.002)
+    raise TimeoutError("rendezvous file %s did not appear" % path)
+
+
+def file_rendezvous_cleanup(rank):
+    import os
+    import shutil
+    if rank == 0:
+        shutil.rmtree(os.path.join("/tmp", "voxcarve_rdzv_%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"))),
+                      ignore_errors=True)
+
+
 def carve_slab(engine, grid, n_ranks, rank, **carve_kwargs):
     """Restrict ``engine`` to rank's slab and carve it; returns the local survivor count."""
     z0, z1 = slab_range(grid[2], n_ranks, rank)
