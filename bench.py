@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--prewarm-seconds", type=float, default=1.0,
                     help="untimed launches before the W warm-up steps so the clocks have ramped (a cold device ran "
                          "the same kernels up to 19 %% slower)")
+    ap.add_argument("--depth", type=int, choices=(1, 2), default=2,
+                    help="steps in flight: 2 overlaps the compaction of step i with the carve kernel of step i+1")
     ap.add_argument("--transport", choices=("rccl", "host"), default="rccl",
                     help="N>1 survivor exchange: rccl (device, default) or host (gloo; rehearsal on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0")
@@ -107,13 +109,13 @@ class Group:
             self.dist.destroy_process_group()
 
 
-def run_mode(eng, grp, mode, steps, warmup, multi, host_transport=None):
+def run_mode(eng, grp, mode, steps, warmup, multi, host_transport=None, depth=2):
     """W untimed + K timed steps of one mode; returns (seconds, kernel ms avg, survivors, total)."""
     eng.set_option("lut_hier", 0 if mode == "lut_stream" else 1)
     mode = "lut" if mode == "lut_stream" else mode
 
-    def step(i):
-        n = eng.carve(slot=i % N_SLOTS, mode=mode)
+    def finish():
+        n = eng.carve_end()
         if multi and host_transport is not None:
             _, total = host_transport.allgather_records(eng.fetch_records())
             return n, total
@@ -122,15 +124,28 @@ def run_mode(eng, grp, mode, steps, warmup, multi, host_transport=None):
             return n, total
         return n, n
 
-    for i in range(warmup):
-        step(i)
+    def run(first, count):
+        """`count` steps; with depth 2 step i+1 is enqueued before step i is completed, so its carve
+        kernel runs beside the compaction of step i (second stream)."""
+        last = (0, 0)
+        if depth <= 1:
+            for i in range(count):
+                eng.carve_begin(slot=(first + i) % N_SLOTS, mode=mode)
+                last = finish()
+            return last
+        eng.carve_begin(slot=first % N_SLOTS, mode=mode)
+        for i in range(1, count):
+            eng.carve_begin(slot=(first + i) % N_SLOTS, mode=mode)
+            last = finish()
+        return finish()
+
+    if warmup:
+        run(0, warmup)
     eng.synchronize()
     grp.barrier()
     eng.timing(reset=True)
     t0 = time.perf_counter()
-    last = (0, 0)
-    for i in range(steps):
-        last = step(warmup + i)
+    last = run(warmup, steps)
     eng.synchronize()
     grp.barrier()
     dt = grp.max(time.perf_counter() - t0)
@@ -207,7 +222,7 @@ def main():
     results = {}
     order = [args.mode] + [m for m in ("lut", "lut_stream", "fused") if m != args.mode]
     for mode in order:
-        dt, kernel_ms, n_local, n_total, tm = run_mode(eng, grp, mode, args.steps, args.warmup, multi, host_transport)
+        dt, kernel_ms, n_local, n_total, tm = run_mode(eng, grp, mode, args.steps, args.warmup, multi, host_transport, args.depth)
         results[mode] = {"seconds": dt, "kernel_ms": kernel_ms, "survivors": int(n_total),
                          "compact_ms": tm["compact_ms"], "gather_ms": tm["gather_ms"], "tm": tm}
 
@@ -280,7 +295,8 @@ def main():
         "config": {"workload": "%d^3 voxel grid x %d cams (%dx%d masks), z-slab split over %d GPU(s), mode=%s, "
                                "ordered survivor list + colour%s" % (G, C, W, H, grp.world, args.mode,
                                                                      (" + RCCL all-gather" if host_transport is None else " + host (gloo) gather") if multi else ""),
-                   "grid": [G, G, G], "cameras": C, "mode": args.mode, "survivors": head["survivors"]},
+                   "grid": [G, G, G], "cameras": C, "mode": args.mode, "survivors": head["survivors"],
+                   "steps_in_flight": args.depth},
         "roofline": roof,
         "roofline_stream": roof_stream,
         "other_modes": others,

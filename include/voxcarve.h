@@ -108,6 +108,12 @@ int vc_project(vc_ctx *ctx, uint32_t cam, const double *xyz, uint64_t n, double 
  * -1 for none.  Leaves the ordered survivor records on the device; *n_out = count. */
 int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int mode,
              uint32_t flags, uint64_t *n_out);
+/* The same step split in two so that consecutive steps overlap (the compaction of step i runs on
+ * a second stream beside the carve kernel of step i+1).  At most two steps may be in flight;
+ * vc_carve_end completes the OLDEST one, whose records are then what vc_fetch_* / vc_allgather
+ * read until the next vc_carve_end (fetch them before beginning two more steps). */
+int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int mode, uint32_t flags);
+int vc_carve_end(vc_ctx *ctx, uint64_t *n_out);
 /* Survivors of the last carve: idx u32 [S] (global linear index, ascending), rgb u8 [S,3]
  * (RGB order, i.e. the reference's BGR[::-1]) and seen u8 [S] (1 if the colour camera
  * sees the voxel -- the reference raises KeyError when it does not).  Any may be NULL. */

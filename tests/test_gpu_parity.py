@@ -233,6 +233,44 @@ def test_simulated_slab_split_equals_full_grid(eng, cams, masks, frames):
     assert eng.carve() == 0
 
 
+def test_overlapped_steps_begin_end(eng, cams, masks, frames):
+    """Two steps in flight (compaction of step i beside the carve kernel of step i+1) give the
+    records of the one-at-a-time calls, in order, for both modes."""
+    from voxcarve._lib import VoxcarveError
+    grid = (128, 128, 128)
+    setup_real(eng, cams, masks, frames, grid)
+    rolled = [np.roll(m, 7, axis=1) for m in masks]
+    eng.upload_masks(rolled, slot=1)
+    eng.upload_frame(1, frames[1], slot=1)
+    eng.build_lut()
+    for mode in ("lut", "fused"):
+        want = []
+        for slot in (0, 1, 0, 1, 1):
+            eng.carve(slot=slot, mode=mode)
+            want.append(eng.fetch_records())
+        assert not np.array_equal(want[0], want[1])
+        got = []
+        eng.carve_begin(slot=0, mode=mode)
+        for slot in (1, 0, 1, 1):
+            eng.carve_begin(slot=slot, mode=mode)
+            assert eng.carve_end() == want[len(got)].size
+            got.append(eng.fetch_records())
+        with pytest.raises(VoxcarveError, match="in flight"):
+            eng.carve(slot=0, mode=mode)                    # the synchronous call refuses to jump the queue
+        assert eng.carve_end() == want[4].size
+        got.append(eng.fetch_records())
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b)
+        with pytest.raises(VoxcarveError, match="no carve step"):
+            eng.carve_end()
+    eng.carve_begin(slot=0)
+    eng.carve_begin(slot=1)
+    with pytest.raises(VoxcarveError, match="already in flight"):
+        eng.carve_begin(slot=0)
+    eng.carve_end()
+    eng.carve_end()
+
+
 def test_rccl_allgather_single_rank(eng, cams, masks, frames):
     """The RCCL path (dlopen, communicator, counts all-gather, grouped broadcast) with one rank."""
     import voxcarve

@@ -56,6 +56,8 @@ SIGNATURES = {
     "vc_project": (ctypes.c_int, [c_ctx, ctypes.c_uint32, c_f64p, ctypes.c_uint64, c_f64p]),
     "vc_carve": (ctypes.c_int, [c_ctx, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_int,
                                 ctypes.c_uint32, c_u64p]),
+    "vc_carve_begin": (ctypes.c_int, [c_ctx, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_uint32]),
+    "vc_carve_end": (ctypes.c_int, [c_ctx, c_u64p]),
     "vc_fetch": (ctypes.c_int, [c_ctx, c_u32p, c_u8p, c_u8p]),
     "vc_fetch_records": (ctypes.c_int, [c_ctx, c_u64p]),
     "vc_host_alloc": (ctypes.c_int, [c_ctx, ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p)]),

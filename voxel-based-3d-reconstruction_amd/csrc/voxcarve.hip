@@ -115,9 +115,27 @@ void linspace(double lo, double hi, uint32_t n, std::vector<double> &out)
 
 }  // namespace
 
+// One carve step's device state.  Two of them exist so that the compaction of step i (second
+// stream) overlaps the carve kernel of step i+1 (vc_carve_begin / vc_carve_end).
+struct StepBuf {
+    DevBuf<uint64_t> words;
+    DevBuf<uint32_t> groupcnt, groupoff;
+    DevBuf<uint64_t> blocksum, blockoff;     // blockoff[nscan] = total
+    DevBuf<uint64_t> records;
+    uint64_t *h_total = nullptr;             // pinned
+    hipEvent_t e0 = nullptr, e_first = nullptr, e1 = nullptr, e2 = nullptr;
+    bool pending = false, used = false;
+    EmitParams emit;                         // kept for a re-run after a records regrow
+    bool allseen = false, want_vm = false, has_first = false;
+    uint64_t n = 0, survivors = 0;
+};
+
 struct vc_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;           // scan + emit of a step, behind the carve kernel's event
+    StepBuf sb[2];
+    int head = 0, npending = 0, cur = -1;    // next set to issue into, steps in flight, set holding the fetched result
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::string err;
 
@@ -140,11 +158,6 @@ struct vc_ctx {
     DevBuf<uint64_t> d_bbox;         // [C][n_pad/64] per-word pixel boxes (built with the LUT)
     uint32_t gshift = 2, gws = 1, gh = 1;   // block grid geometry for H x W
     bool lut_valid = false;
-    DevBuf<uint64_t> d_words;
-    DevBuf<uint32_t> d_groupcnt;
-    DevBuf<uint32_t> d_groupoff;
-    DevBuf<uint64_t> d_blockoff;     // exclusive scan of the block sums, [nscan] = total
-    DevBuf<uint64_t> d_blocksum;     // survivors per scan block
     DevBuf<uint32_t> d_est;          // per-camera pass counts of k_estimate
     uint32_t *h_est = nullptr;       // pinned, VC_MAX_CAMERAS
     // tuning knobs (vc_set_option); defaults are the measured best on MI355X
@@ -161,9 +174,8 @@ struct vc_ctx {
     int fused_hier = 1;              // VC_MODE_FUSED: interval-arithmetic word rejection (needs ny % 64 == 0)
     int lut_hier = 1;                // VC_MODE_LUT: hierarchical kernel (boxes + block grid) instead of stream + refine
     DevBuf<uint16_t> d_viewmask;
-    DevBuf<uint64_t> d_records;
     DevBuf<double> d_scratch;
-    uint64_t *h_total = nullptr;     // pinned
+    uint64_t *h_total = nullptr;     // pinned scalar (all-gather count)
     bool viewmask_valid = false, carved = false;
     uint64_t survivors = 0;
 
@@ -262,13 +274,27 @@ int slot_at(vc_ctx *ctx, uint32_t slot, Slot **out)
 
 uint32_t grid_for(uint64_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
 
+
+constexpr int kEmitBatch = 4;              // survivors per lane in flight together in k_emit_words
+
+int launch_emit(vc_ctx *ctx, StepBuf &sb, hipStream_t st)
+{
+    const EmitParams &e = sb.emit;
+    const dim3 eg((e.ngroups + 3) / 4), block(kBlock);
+    if (e.lut && sb.allseen) hipLaunchKernelGGL((k_emit_words<true, true, kEmitBatch>), eg, block, 0, st, e);
+    else if (e.lut) hipLaunchKernelGGL((k_emit_words<true, false, kEmitBatch>), eg, block, 0, st, e);
+    else if (sb.allseen) hipLaunchKernelGGL((k_emit_words<false, true, kEmitBatch>), eg, block, 0, st, e);
+    else hipLaunchKernelGGL((k_emit_words<false, false, kEmitBatch>), eg, block, 0, st, e);
+    VC_HIP(ctx, hipGetLastError());
+    return VC_OK;
+}
+
 constexpr uint32_t kMaxScanBlocks = 1024;  // 2^32 voxels / 4096 per group / 1024 groups per scan block
 constexpr int kSub = 4;                    // 64-voxel sub-chunks per wavefront chunk (fused kernel)
 constexpr size_t kLdsBytes = 160 * 1024;   // LDS per CU on gfx950
 constexpr size_t kMaxFirstLds = 64 * 1024; // static limit of one workgroup's dynamic LDS without opt-in
 constexpr uint32_t kPersistentBlocks = 256 * 8;   // 256 CUs x 8 workgroups of 4 waves = full occupancy
 constexpr uint32_t kEstimateSamples = 1u << 16;
-constexpr int kEmitBatch = 4;              // survivors per lane in flight together in k_emit_words
 
 }  // namespace
 
@@ -305,6 +331,15 @@ int vc_create(int device, vc_ctx **out)
     ctx->device = device;
     memset(&ctx->tm, 0, sizeof ctx->tm);
     hipError_t e1 = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e1 == hipSuccess) e1 = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
+    for (int k = 0; k < 2 && e1 == hipSuccess; ++k) {
+        StepBuf &b = ctx->sb[k];
+        e1 = hipEventCreate(&b.e0);
+        if (e1 == hipSuccess) e1 = hipEventCreate(&b.e_first);
+        if (e1 == hipSuccess) e1 = hipEventCreate(&b.e1);
+        if (e1 == hipSuccess) e1 = hipEventCreate(&b.e2);
+        if (e1 == hipSuccess) e1 = hipHostMalloc(reinterpret_cast<void **>(&b.h_total), sizeof(uint64_t), hipHostMallocDefault);
+    }
     for (int i = 0; i < 4 && e1 == hipSuccess; ++i) e1 = hipEventCreate(&ctx->ev[i]);
     if (e1 == hipSuccess) e1 = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_total), sizeof(uint64_t), hipHostMallocDefault);
     if (e1 == hipSuccess) e1 = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_est), sizeof(uint32_t) * VC_MAX_CAMERAS, hipHostMallocDefault);
@@ -324,16 +359,25 @@ int vc_destroy(vc_ctx *ctx)
     if (!ctx) return VC_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
     for (Slot &s : ctx->slots) { release(s.bits); release(s.frames); release(s.grid); }
-    release(ctx->d_axes); release(ctx->d_stage); release(ctx->d_lut); release(ctx->d_bbox); release(ctx->d_words);
-    release(ctx->d_groupcnt); release(ctx->d_groupoff); release(ctx->d_blockoff); release(ctx->d_viewmask);
-    release(ctx->d_records); release(ctx->d_scratch); release(ctx->d_counts); release(ctx->d_gathered);
+    release(ctx->d_axes); release(ctx->d_stage); release(ctx->d_lut); release(ctx->d_bbox);
+    for (StepBuf &b : ctx->sb) {
+        release(b.words); release(b.groupcnt); release(b.groupoff); release(b.blocksum); release(b.blockoff); release(b.records);
+        if (b.h_total) (void)hipHostFree(b.h_total);
+        if (b.e0) (void)hipEventDestroy(b.e0);
+        if (b.e_first) (void)hipEventDestroy(b.e_first);
+        if (b.e1) (void)hipEventDestroy(b.e1);
+        if (b.e2) (void)hipEventDestroy(b.e2);
+    }
+    release(ctx->d_viewmask); release(ctx->d_scratch); release(ctx->d_counts); release(ctx->d_gathered);
     if (ctx->h_total) (void)hipHostFree(ctx->h_total);
     if (ctx->h_est) (void)hipHostFree(ctx->h_est);
-    release(ctx->d_blocksum); release(ctx->d_est);
+    release(ctx->d_est);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
     for (int i = 0; i < 4; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return VC_OK;
@@ -529,11 +573,10 @@ int vc_project(vc_ctx *ctx, uint32_t cam, const double *xyz, uint64_t n, double 
     return VC_OK;
 }
 
-int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int mode, uint32_t flags,
-             uint64_t *n_out)
+int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int mode, uint32_t flags)
 {
-    if (!ctx || !n_out) return VC_ERR_ARG;
-    *n_out = 0;
+    if (!ctx) return VC_ERR_ARG;
+    if (ctx->npending >= 2) return fail(ctx, VC_ERR_ARG, "two carve steps are already in flight: call vc_carve_end");
     if (!ctx->have_grid || !ctx->have_cams) return fail(ctx, VC_ERR_ARG, "grid and cameras must be set before vc_carve");
     if (slot >= ctx->slots.size() || !ctx->slots[slot].have_masks)
         return fail(ctx, VC_ERR_ARG, "no masks uploaded in slot %u", slot);
@@ -545,31 +588,35 @@ int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int 
     Slot &s = ctx->slots[slot];
     const uint64_t n = ctx->n_voxels();
     const bool want_vm = (flags & VC_FLAG_VIEWMASK) != 0;
-    ctx->carved = false; ctx->gathered = false; ctx->viewmask_valid = false;
-    ctx->survivors = 0;
+    ctx->gathered = false;
     ctx->tm.voxels = n;
-    if (n == 0) { ctx->carved = true; ctx->tm.survivors = 0; return VC_OK; }
+    StepBuf &sb = ctx->sb[ctx->head];
+    sb.n = n; sb.survivors = 0; sb.want_vm = want_vm; sb.has_first = false;
+    sb.allseen = min_views >= ctx->C;
+    if (n == 0) { sb.pending = true; sb.used = false; ctx->head ^= 1; ctx->npending++; return VC_OK; }
+    // this set's previous step must have left the device before its buffers are reused
+    if (sb.used) VC_HIP(ctx, hipStreamWaitEvent(ctx->stream, sb.e2, 0));
 
     const uint64_t nwords = (n + 63) / 64;
     const uint64_t n_pad = (n + kLutPad - 1) / kLutPad * kLutPad;
     const uint32_t ngroups = (uint32_t)(n_pad / (64 * kGroupWords));
     const uint32_t nscan = (ngroups + kScanBlock - 1) / kScanBlock;
-    VC_TRY(ensure(ctx, ctx->d_words, n_pad / 64));
-    VC_TRY(ensure(ctx, ctx->d_groupcnt, ngroups));
-    VC_TRY(ensure(ctx, ctx->d_groupoff, ngroups));
-    VC_TRY(ensure(ctx, ctx->d_blocksum, kMaxScanBlocks));
-    VC_TRY(ensure(ctx, ctx->d_blockoff, kMaxScanBlocks + 1));
+    VC_TRY(ensure(ctx, sb.words, n_pad / 64));
+    VC_TRY(ensure(ctx, sb.groupcnt, ngroups));
+    VC_TRY(ensure(ctx, sb.groupoff, ngroups));
+    VC_TRY(ensure(ctx, sb.blocksum, kMaxScanBlocks));
+    VC_TRY(ensure(ctx, sb.blockoff, kMaxScanBlocks + 1));
     VC_TRY(ensure(ctx, ctx->d_est, VC_MAX_CAMERAS));
     if (want_vm) VC_TRY(ensure(ctx, ctx->d_viewmask, n));
-    if (!ctx->d_records.ptr) VC_TRY(ensure(ctx, ctx->d_records, (size_t)(n / 16 + 1024)));
+    if (!sb.records.ptr) VC_TRY(ensure(ctx, sb.records, (size_t)(n / 16 + 1024)));
 
     CarveParams p;
     fill_params(ctx, p);
     p.maskbits = s.bits.ptr;
     p.lut = ctx->d_lut.ptr;
     p.blockgrid = s.grid.ptr;
-    p.words = ctx->d_words.ptr;
-    p.groupcnt = ctx->d_groupcnt.ptr;
+    p.words = sb.words.ptr;
+    p.groupcnt = sb.groupcnt.ptr;
     p.viewmask = ctx->d_viewmask.ptr;
     p.min_views = min_views;
 
@@ -595,7 +642,7 @@ int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int 
     }
     for (uint32_t c = 0; c < ctx->C; ++c) p.order[c] = (fast && ctx->reorder) ? s.order[c] : c;
 
-    VC_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    VC_HIP(ctx, hipEventRecord(sb.e0, ctx->stream));
     const dim3 block(kBlock);
     if (fast) {
         const uint64_t nchunks = (n + 64 * kSub - 1) / (64 * kSub);
@@ -615,7 +662,8 @@ int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int 
             else if (ctx->refine_b == 8) hipLaunchKernelGGL((k_lut_refine<8, true, 2, false>), rgrid, block, lds, ctx->stream, p);
             else if (wl == 1) hipLaunchKernelGGL((k_lut_refine<16, true, 1, false>), rgrid, block, lds, ctx->stream, p);
             else hipLaunchKernelGGL((k_lut_refine<16, true, 2, false>), rgrid, block, lds, ctx->stream, p);
-            VC_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+            VC_HIP(ctx, hipEventRecord(sb.e_first, ctx->stream));
+            sb.has_first = true;
         } else if (mode == VC_MODE_LUT) {
             const size_t lds = (size_t)ctx->mwords * sizeof(uint32_t);
             const int kv = ctx->first_kv;
@@ -630,7 +678,8 @@ int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int 
             else if (kv == 4) hipLaunchKernelGGL((k_lut_first<4>), fgrid, fblock, lds, ctx->stream, p);
             else hipLaunchKernelGGL((k_lut_first<2>), fgrid, fblock, lds, ctx->stream, p);
             VC_HIP(ctx, hipGetLastError());
-            VC_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+            VC_HIP(ctx, hipEventRecord(sb.e_first, ctx->stream));
+            sb.has_first = true;
             const uint64_t groups = p.n_pad / 4096;
             const uint64_t rwant = (groups + 3) / 4;
             const uint64_t rmax = 256ull * (uint64_t)ctx->refine_blocks_per_cu;
@@ -659,27 +708,29 @@ int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int 
         }
     }
     VC_HIP(ctx, hipGetLastError());
-    VC_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    VC_HIP(ctx, hipEventRecord(sb.e1, ctx->stream));
 
-    // kernels that do not know their group totals (fused, generic, the padded tail) get them counted
+    // ---- compaction on the second stream, behind the carve kernel
+    hipStream_t s2 = ctx->stream2;
+    VC_HIP(ctx, hipStreamWaitEvent(s2, sb.e1, 0));
+    // kernels that do not know their group totals (fused, generic) get them counted
     const bool counted = fast && (mode == VC_MODE_LUT || (ctx->ny % 64 == 0 && ctx->fused_hier));
     if (!counted) {
-        hipLaunchKernelGGL(k_count_groups, dim3((ngroups + 3) / 4), block, 0, ctx->stream, ctx->d_words.ptr, nwords,
-                           ngroups, ctx->d_groupcnt.ptr);
+        hipLaunchKernelGGL(k_count_groups, dim3((ngroups + 3) / 4), block, 0, s2, sb.words.ptr, nwords, ngroups,
+                           sb.groupcnt.ptr);
         VC_HIP(ctx, hipGetLastError());
     }
-    hipLaunchKernelGGL(k_scan_groups, dim3(nscan), dim3(kScanBlock), 0, ctx->stream, ctx->d_groupcnt.ptr, ngroups,
-                       ctx->d_groupoff.ptr, ctx->d_blocksum.ptr);
+    hipLaunchKernelGGL(k_scan_groups, dim3(nscan), dim3(kScanBlock), 0, s2, sb.groupcnt.ptr, ngroups, sb.groupoff.ptr,
+                       sb.blocksum.ptr);
     VC_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(kScanBlock), 0, ctx->stream, ctx->d_blocksum.ptr, nscan,
-                       ctx->d_blockoff.ptr);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(kScanBlock), 0, s2, sb.blocksum.ptr, nscan, sb.blockoff.ptr);
     VC_HIP(ctx, hipGetLastError());
-    VC_HIP(ctx, hipMemcpyAsync(ctx->h_total, ctx->d_blockoff.ptr + nscan, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    VC_HIP(ctx, hipMemcpyAsync(sb.h_total, sb.blockoff.ptr + nscan, sizeof(uint64_t), hipMemcpyDeviceToHost, s2));
 
-    EmitParams e;
+    EmitParams &e = sb.emit;
     memset(&e, 0, sizeof e);
     e.xs = p.xs; e.ys = p.ys; e.zs = p.zs;
-    e.words = ctx->d_words.ptr; e.groupcnt = ctx->d_groupcnt.ptr; e.groupoff = ctx->d_groupoff.ptr; e.blockoff = ctx->d_blockoff.ptr;
+    e.words = sb.words.ptr; e.groupcnt = sb.groupcnt.ptr; e.groupoff = sb.groupoff.ptr; e.blockoff = sb.blockoff.ptr;
     e.n = n; e.i0 = ctx->i0(); e.ngroups = ngroups;
     e.nx = ctx->nx; e.ny = ctx->ny; e.z0 = ctx->z0; e.H = ctx->H; e.W = ctx->W;
     if (color_cam >= 0) {
@@ -690,41 +741,71 @@ int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int 
             e.frame = s.frames.ptr + (size_t)color_cam * ctx->H * ctx->W;
         if (mode == VC_MODE_LUT) e.lut = ctx->d_lut.ptr + (size_t)color_cam * p.n_pad;
     }
-    uint64_t total = 0;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        e.records = ctx->d_records.ptr;
-        e.capacity = ctx->d_records.cap;
-        {
-            const dim3 eg((ngroups + 3) / 4);
-            const bool allseen = min_views >= ctx->C;
-            if (e.lut && allseen) hipLaunchKernelGGL((k_emit_words<true, true, kEmitBatch>), eg, block, 0, ctx->stream, e);
-            else if (e.lut) hipLaunchKernelGGL((k_emit_words<true, false, kEmitBatch>), eg, block, 0, ctx->stream, e);
-            else if (allseen) hipLaunchKernelGGL((k_emit_words<false, true, kEmitBatch>), eg, block, 0, ctx->stream, e);
-            else hipLaunchKernelGGL((k_emit_words<false, false, kEmitBatch>), eg, block, 0, ctx->stream, e);
-        }
-        VC_HIP(ctx, hipGetLastError());
-        VC_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
-        VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        total = *ctx->h_total;
-        if (total <= ctx->d_records.cap) break;
-        if (attempt == 1) return fail(ctx, VC_ERR_HIP, "survivor buffer still too small after regrow");
-        VC_TRY(ensure(ctx, ctx->d_records, (size_t)(total + total / 8 + 1024)));
-    }
-    ctx->survivors = total;
-    float ms = 0;
-    VC_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
-    ctx->tm.carve_ms = ms;
-    ctx->tm.first_ms = 0;
-    if (fast && mode == VC_MODE_LUT) VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.first_ms, ctx->ev[0], ctx->ev[3]));
-    ctx->tm.first_ms_sum += ctx->tm.first_ms;
-    ctx->tm.carve_ms_sum += ms;
-    ctx->tm.carve_launches += 1;
-    VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.compact_ms, ctx->ev[1], ctx->ev[2]));
-    ctx->tm.survivors = ctx->survivors;
-    ctx->carved = true;
-    ctx->viewmask_valid = want_vm;
-    *n_out = ctx->survivors;
+    e.records = sb.records.ptr;
+    e.capacity = sb.records.cap;
+    VC_TRY(launch_emit(ctx, sb, s2));
+    VC_HIP(ctx, hipEventRecord(sb.e2, s2));
+    sb.pending = true;
+    sb.used = true;
+    ctx->head ^= 1;
+    ctx->npending++;
     return VC_OK;
+}
+
+// Completes the oldest step in flight: its survivor count, and its records become what the
+// vc_fetch_* functions and vc_allgather read.
+int vc_carve_end(vc_ctx *ctx, uint64_t *n_out)
+{
+    if (!ctx || !n_out) return VC_ERR_ARG;
+    *n_out = 0;
+    if (ctx->npending == 0) return fail(ctx, VC_ERR_ARG, "no carve step in flight");
+    VC_HIP(ctx, hipSetDevice(ctx->device));
+    const int k = (ctx->npending == 2) ? ctx->head : (ctx->head ^ 1);      // oldest pending set
+    StepBuf &sb = ctx->sb[k];
+    ctx->carved = false; ctx->viewmask_valid = false; ctx->gathered = false;
+    if (sb.n != 0) {
+        VC_HIP(ctx, hipEventSynchronize(sb.e2));
+        uint64_t total = *sb.h_total;
+        if (total > sb.records.cap) {                                      // regrow once, expand again
+            VC_TRY(ensure(ctx, sb.records, (size_t)(total + total / 8 + 1024)));
+            sb.emit.records = sb.records.ptr;
+            sb.emit.capacity = sb.records.cap;
+            VC_TRY(launch_emit(ctx, sb, ctx->stream2));
+            VC_HIP(ctx, hipEventRecord(sb.e2, ctx->stream2));
+            VC_HIP(ctx, hipEventSynchronize(sb.e2));
+        }
+        sb.survivors = total;
+        float ms = 0;
+        VC_HIP(ctx, hipEventElapsedTime(&ms, sb.e0, sb.e1));
+        ctx->tm.carve_ms = ms;
+        ctx->tm.first_ms = 0;
+        if (sb.has_first) VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.first_ms, sb.e0, sb.e_first));
+        ctx->tm.first_ms_sum += ctx->tm.first_ms;
+        ctx->tm.carve_ms_sum += ms;
+        ctx->tm.carve_launches += 1;
+        VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.compact_ms, sb.e1, sb.e2));
+    } else {
+        sb.survivors = 0;
+    }
+    sb.pending = false;
+    ctx->npending--;
+    ctx->cur = k;
+    ctx->survivors = sb.survivors;
+    ctx->tm.survivors = sb.survivors;
+    ctx->carved = true;
+    ctx->viewmask_valid = sb.want_vm;
+    *n_out = sb.survivors;
+    return VC_OK;
+}
+
+int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int mode, uint32_t flags,
+             uint64_t *n_out)
+{
+    if (!ctx || !n_out) return VC_ERR_ARG;
+    *n_out = 0;
+    if (ctx->npending != 0) return fail(ctx, VC_ERR_ARG, "vc_carve with steps in flight: drain them with vc_carve_end");
+    VC_TRY(vc_carve_begin(ctx, slot, min_views, color_cam, mode, flags));
+    return vc_carve_end(ctx, n_out);
 }
 
 // Page-locked host memory for the caller's output buffers: device-to-host copies into it run
@@ -752,7 +833,7 @@ int vc_fetch_records(vc_ctx *ctx, uint64_t *records)
     if (!ctx->carved) return fail(ctx, VC_ERR_ARG, "no carve result to fetch");
     VC_HIP(ctx, hipSetDevice(ctx->device));
     if (ctx->survivors)
-        VC_HIP(ctx, hipMemcpy(records, ctx->d_records.ptr, ctx->survivors * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        VC_HIP(ctx, hipMemcpy(records, ctx->sb[ctx->cur].records.ptr, ctx->survivors * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return VC_OK;
 }
 
@@ -789,7 +870,7 @@ int vc_fetch_occupancy(vc_ctx *ctx, uint8_t *bits)
     if (!ctx->carved) return fail(ctx, VC_ERR_ARG, "no carve result to fetch");
     VC_HIP(ctx, hipSetDevice(ctx->device));
     const uint64_t nwords = (ctx->n_voxels() + 63) / 64;
-    if (nwords) VC_HIP(ctx, hipMemcpy(bits, ctx->d_words.ptr, nwords * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (nwords) VC_HIP(ctx, hipMemcpy(bits, ctx->sb[ctx->cur].words.ptr, nwords * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return VC_OK;
 }
 
@@ -893,13 +974,14 @@ int vc_allgather(vc_ctx *ctx, uint64_t *counts_out, uint64_t *total_out)
     uint64_t total = 0;
     for (int r = 0; r < G; ++r) total += ctx->h_counts[r];
     VC_TRY(ensure(ctx, ctx->d_gathered, (size_t)total));
-    if (!ctx->d_records.ptr) VC_TRY(ensure(ctx, ctx->d_records, 1024));
+    StepBuf &cur = ctx->sb[ctx->cur];
+    if (!cur.records.ptr) VC_TRY(ensure(ctx, cur.records, 1024));
     VC_NCCL(ctx, g_rccl.GroupStart());
     uint64_t disp = 0;
     for (int r = 0; r < G; ++r) {
         const uint64_t cnt = ctx->h_counts[r];
         if (cnt) {
-            ncclResult_t rc = g_rccl.Broadcast(ctx->d_records.ptr, ctx->d_gathered.ptr + disp, cnt, ncclUint64, r,
+            ncclResult_t rc = g_rccl.Broadcast(cur.records.ptr, ctx->d_gathered.ptr + disp, cnt, ncclUint64, r,
                                                ctx->comm, ctx->stream);
             if (rc != ncclSuccess) {
                 g_rccl.GroupEnd();

@@ -139,6 +139,20 @@ class CarveEngine:
         self.count = int(n.value)
         return self.count
 
+    def carve_begin(self, slot=0, min_views=None, color_cam=COLOR_CAMERA_INDEX, mode="fused", viewmask=False):
+        """Enqueue a carve step without waiting (at most two in flight): the compaction of this step
+        overlaps the carve kernel of the next one.  carve_end() completes the oldest step."""
+        mv = self.n_cameras if min_views is None else int(min_views)
+        cc = -1 if color_cam is None else int(color_cam)
+        flags = _lib.VC_FLAG_VIEWMASK if viewmask else 0
+        self._check(self._L.vc_carve_begin(self._ctx, slot, mv, cc, MODES[mode], flags), "vc_carve_begin")
+
+    def carve_end(self):
+        n = ctypes.c_uint64(0)
+        self._check(self._L.vc_carve_end(self._ctx, ctypes.byref(n)), "vc_carve_end")
+        self.count = int(n.value)
+        return self.count
+
     def fetch(self):
         """(idx u32 [S] ascending global linear index, rgb u8 [S,3], seen bool [S])."""
         S = self.count
