@@ -52,7 +52,7 @@ def parse():
                     help="untimed launches before the W warm-up steps so the clocks have ramped (a cold device ran "
                          "the same kernels up to 19 %% slower)")
     ap.add_argument("--depth", type=int, choices=(1, 2), default=2,
-                    help="steps in flight: 2 overlaps the compaction of step i with the carve kernel of step i+1")
+                    help="steps in flight: with 2, step i+1 is queued on the device before the host collects step i")
     ap.add_argument("--transport", choices=("rccl", "host"), default="rccl",
                     help="N>1 survivor exchange: rccl (device, default) or host (gloo; rehearsal on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0")
@@ -125,8 +125,8 @@ def run_mode(eng, grp, mode, steps, warmup, multi, host_transport=None, depth=2)
         return n, n
 
     def run(first, count):
-        """`count` steps; with depth 2 step i+1 is enqueued before step i is completed, so its carve
-        kernel runs beside the compaction of step i (second stream)."""
+        """`count` steps; with depth 2 step i+1 is enqueued before step i is collected, so the device
+        never idles between steps (one stream, same kernels)."""
         last = (0, 0)
         if depth <= 1:
             for i in range(count):

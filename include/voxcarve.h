@@ -108,8 +108,8 @@ int vc_project(vc_ctx *ctx, uint32_t cam, const double *xyz, uint64_t n, double 
  * -1 for none.  Leaves the ordered survivor records on the device; *n_out = count. */
 int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int mode,
              uint32_t flags, uint64_t *n_out);
-/* The same step split in two so that consecutive steps overlap (the compaction of step i runs on
- * a second stream beside the carve kernel of step i+1).  At most two steps may be in flight;
+/* The same step split in two so that step i+1 is queued on the device before the host collects
+ * step i (no idle gap between steps).  At most two steps may be in flight;
  * vc_carve_end completes the OLDEST one, whose records are then what vc_fetch_* / vc_allgather
  * read until the next vc_carve_end (fetch them before beginning two more steps). */
 int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int mode, uint32_t flags);

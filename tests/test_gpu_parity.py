@@ -234,8 +234,8 @@ def test_simulated_slab_split_equals_full_grid(eng, cams, masks, frames):
 
 
 def test_overlapped_steps_begin_end(eng, cams, masks, frames):
-    """Two steps in flight (compaction of step i beside the carve kernel of step i+1) give the
-    records of the one-at-a-time calls, in order, for both modes."""
+    """Two steps in flight (step i+1 queued before step i is collected) give the records of the
+    one-at-a-time calls, in order, for both modes."""
     from voxcarve._lib import VoxcarveError
     grid = (128, 128, 128)
     setup_real(eng, cams, masks, frames, grid)

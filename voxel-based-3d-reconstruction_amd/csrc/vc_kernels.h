@@ -275,17 +275,16 @@ __device__ __forceinline__ bool box_may_hit(const uint32_t *__restrict__ g, uint
 //               then take the exact per-voxel test through all cameras.  Exact: a box with no
 //               foreground block cannot contain a foreground pixel of any of its voxels.
 template <int B, bool HIER, int WL, bool PAIR>
-__global__ __launch_bounds__(kBlock) void k_lut_refine(const CarveParams p)
+__device__ __forceinline__ void lut_refine_body(const CarveParams &p, uint32_t vblock, uint32_t nblocks, uint32_t *s_grid)
 {
-    extern __shared__ uint32_t s_grid[];                          // HIER: [C][gh][gws]
     if (HIER) {
         const uint32_t total = p.C * p.gh * p.gws;
         for (uint32_t i = threadIdx.x; i < total; i += kBlock) s_grid[i] = p.blockgrid[i];
         __syncthreads();
     }
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
-    const uint32_t nwaves = gridDim.x * (kBlock / 64);
+    const uint32_t wave0 = __builtin_amdgcn_readfirstlane((vblock * kBlock + threadIdx.x) >> 6);
+    const uint32_t nwaves = nblocks * (kBlock / 64);
     constexpr uint32_t GW = 64 * WL;                              // words per group (WL per lane)
     const uint32_t ngroups = (uint32_t)(p.n_pad / (64 * GW));
     const uint64_t nwords = p.n_pad >> 6;
@@ -406,6 +405,13 @@ __global__ __launch_bounds__(kBlock) void k_lut_refine(const CarveParams p)
             if (lane == 0) p.groupcnt[(uint64_t)g * WL + w] = cnt;
         }
     }
+}
+
+template <int B, bool HIER, int WL, bool PAIR>
+__global__ __launch_bounds__(kBlock) void k_lut_refine(const CarveParams p)
+{
+    extern __shared__ uint32_t s_grid[];                          // HIER: [C][gh][gws]
+    lut_refine_body<B, HIER, WL, PAIR>(p, blockIdx.x, gridDim.x, s_grid);
 }
 
 // ---------------------------------------------------------------- fused carve
@@ -782,13 +788,13 @@ __device__ __forceinline__ uint32_t select_bit(uint64_t x, uint32_t r)
 // the colour camera's test is known to pass; FROM_LUT: its pixel offset is read from the table
 // instead of being re-projected.
 template <bool FROM_LUT, bool ALLSEEN, int EU>
-__global__ __launch_bounds__(kBlock) void k_emit_words(const EmitParams p)
+__device__ __forceinline__ void emit_body(const EmitParams &p, uint32_t vblock)
 {
     const uint32_t lane = threadIdx.x & 63u;
     // One wave per group, no loop: the grid is the group list and the hardware dispatcher
     // balances the busy groups of the compact hull; an empty group (5 of 6) costs its wave one
     // scalar load of the group count.
-    const uint32_t g = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
+    const uint32_t g = __builtin_amdgcn_readfirstlane((vblock * kBlock + threadIdx.x) >> 6);
     if (g >= p.ngroups) return;
     if (p.groupcnt[g] == 0) return;
     const uint64_t nwords = (p.n + 63) >> 6;
@@ -848,6 +854,12 @@ __global__ __launch_bounds__(kBlock) void k_emit_words(const EmitParams p)
             }
         }
     }
+}
+
+template <bool FROM_LUT, bool ALLSEEN, int EU>
+__global__ __launch_bounds__(kBlock) void k_emit_words(const EmitParams p)
+{
+    emit_body<FROM_LUT, ALLSEEN, EU>(p, blockIdx.x);
 }
 
 }  // namespace vc

@@ -115,8 +115,8 @@ void linspace(double lo, double hi, uint32_t n, std::vector<double> &out)
 
 }  // namespace
 
-// One carve step's device state.  Two of them exist so that the compaction of step i (second
-// stream) overlaps the carve kernel of step i+1 (vc_carve_begin / vc_carve_end).
+// One carve step's device state.  Two of them exist so that step i+1 can be enqueued before the
+// host has collected step i (vc_carve_begin / vc_carve_end): the device never idles between steps.
 struct StepBuf {
     DevBuf<uint64_t> words;
     DevBuf<uint32_t> groupcnt, groupoff;
@@ -133,7 +133,6 @@ struct StepBuf {
 struct vc_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;           // scan + emit of a step, behind the carve kernel's event
     StepBuf sb[2];
     int head = 0, npending = 0, cur = -1;    // next set to issue into, steps in flight, set holding the fetched result
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -293,7 +292,6 @@ constexpr uint32_t kMaxScanBlocks = 1024;  // 2^32 voxels / 4096 per group / 102
 constexpr int kSub = 4;                    // 64-voxel sub-chunks per wavefront chunk (fused kernel)
 constexpr size_t kLdsBytes = 160 * 1024;   // LDS per CU on gfx950
 constexpr size_t kMaxFirstLds = 64 * 1024; // static limit of one workgroup's dynamic LDS without opt-in
-constexpr uint32_t kPersistentBlocks = 256 * 8;   // 256 CUs x 8 workgroups of 4 waves = full occupancy
 constexpr uint32_t kEstimateSamples = 1u << 16;
 
 }  // namespace
@@ -331,7 +329,6 @@ int vc_create(int device, vc_ctx **out)
     ctx->device = device;
     memset(&ctx->tm, 0, sizeof ctx->tm);
     hipError_t e1 = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    if (e1 == hipSuccess) e1 = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
     for (int k = 0; k < 2 && e1 == hipSuccess; ++k) {
         StepBuf &b = ctx->sb[k];
         e1 = hipEventCreate(&b.e0);
@@ -359,7 +356,6 @@ int vc_destroy(vc_ctx *ctx)
     if (!ctx) return VC_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
     for (Slot &s : ctx->slots) { release(s.bits); release(s.frames); release(s.grid); }
     release(ctx->d_axes); release(ctx->d_stage); release(ctx->d_lut); release(ctx->d_bbox);
@@ -377,7 +373,6 @@ int vc_destroy(vc_ctx *ctx)
     release(ctx->d_est);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
     for (int i = 0; i < 4; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
-    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return VC_OK;
@@ -594,8 +589,6 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     sb.n = n; sb.survivors = 0; sb.want_vm = want_vm; sb.has_first = false;
     sb.allseen = min_views >= ctx->C;
     if (n == 0) { sb.pending = true; sb.used = false; ctx->head ^= 1; ctx->npending++; return VC_OK; }
-    // this set's previous step must have left the device before its buffers are reused
-    if (sb.used) VC_HIP(ctx, hipStreamWaitEvent(ctx->stream, sb.e2, 0));
 
     const uint64_t nwords = (n + 63) / 64;
     const uint64_t n_pad = (n + kLutPad - 1) / kLutPad * kLutPad;
@@ -710,9 +703,8 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     VC_HIP(ctx, hipGetLastError());
     VC_HIP(ctx, hipEventRecord(sb.e1, ctx->stream));
 
-    // ---- compaction on the second stream, behind the carve kernel
-    hipStream_t s2 = ctx->stream2;
-    VC_HIP(ctx, hipStreamWaitEvent(s2, sb.e1, 0));
+    // ---- compaction: group counts -> two-level scan -> record expansion
+    hipStream_t s2 = ctx->stream;
     // kernels that do not know their group totals (fused, generic) get them counted
     const bool counted = fast && (mode == VC_MODE_LUT || (ctx->ny % 64 == 0 && ctx->fused_hier));
     if (!counted) {
@@ -770,8 +762,8 @@ int vc_carve_end(vc_ctx *ctx, uint64_t *n_out)
             VC_TRY(ensure(ctx, sb.records, (size_t)(total + total / 8 + 1024)));
             sb.emit.records = sb.records.ptr;
             sb.emit.capacity = sb.records.cap;
-            VC_TRY(launch_emit(ctx, sb, ctx->stream2));
-            VC_HIP(ctx, hipEventRecord(sb.e2, ctx->stream2));
+            VC_TRY(launch_emit(ctx, sb, ctx->stream));
+            VC_HIP(ctx, hipEventRecord(sb.e2, ctx->stream));
             VC_HIP(ctx, hipEventSynchronize(sb.e2));
         }
         sb.survivors = total;

@@ -140,8 +140,8 @@ class CarveEngine:
         return self.count
 
     def carve_begin(self, slot=0, min_views=None, color_cam=COLOR_CAMERA_INDEX, mode="fused", viewmask=False):
-        """Enqueue a carve step without waiting (at most two in flight): the compaction of this step
-        overlaps the carve kernel of the next one.  carve_end() completes the oldest step."""
+        """Enqueue a carve step without waiting (at most two in flight), so the device has the next
+        step queued while the host collects this one.  carve_end() completes the oldest step."""
         mv = self.n_cameras if min_views is None else int(min_views)
         cc = -1 if color_cam is None else int(color_cam)
         flags = _lib.VC_FLAG_VIEWMASK if viewmask else 0
