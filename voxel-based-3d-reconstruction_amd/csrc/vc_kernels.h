@@ -862,4 +862,73 @@ __global__ __launch_bounds__(kBlock) void k_emit_words(const EmitParams p)
     emit_body<FROM_LUT, ALLSEEN, EU>(p, blockIdx.x);
 }
 
+// Variant of the expansion with lanes = the 64 voxels of a word: a survivor's rank inside its
+// word is the count of set bits below its lane (no search at all), at the price of idle lanes in
+// sparse words (the hull's words are dense: ~44 of 64 bits).  EB words are expanded together.
+template <bool FROM_LUT, bool ALLSEEN, int EB>
+__global__ __launch_bounds__(kBlock) void k_emit_lanes(const EmitParams p)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t g = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
+    if (g >= p.ngroups) return;
+    if (p.groupcnt[g] == 0) return;
+    const uint64_t nwords = (p.n + 63) >> 6;
+    const uint64_t out0 = p.blockoff[g / kScanBlock] + p.groupoff[g];
+    const uint64_t gw = (uint64_t)g * kGroupWords;
+    const uint64_t mine = (gw + lane < nwords) ? p.words[gw + lane] : 0ull;
+    const uint32_t c = (uint32_t)__popcll(mine);
+    const uint32_t wstart = wave_inclusive_scan(c, lane) - c;           // first record of my word in the group
+    const uint64_t below = (1ull << lane) - 1ull;
+    uint64_t nz = __ballot(mine != 0);
+    while (nz != 0) {                                                   // wave-uniform
+        uint32_t li[EB], ws[EB];
+        uint64_t wv[EB];
+#pragma unroll
+        for (int b = 0; b < EB; ++b) {
+            li[b] = 0; wv[b] = 0; ws[b] = 0;
+            if (nz != 0) {
+                li[b] = (uint32_t)__builtin_ctzll(nz);
+                nz &= nz - 1;
+                const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, (int)li[b]);
+                const uint32_t whi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), (int)li[b]);
+                wv[b] = ((uint64_t)whi << 32) | wlo;
+                ws[b] = (uint32_t)__builtin_amdgcn_readlane((int)wstart, (int)li[b]);
+            }
+        }
+        int32_t off[EB];
+#pragma unroll
+        for (int b = 0; b < EB; ++b) {
+            off[b] = -1;
+            if (p.has_cam && ((wv[b] >> lane) & 1ull)) {
+                const uint32_t j = (uint32_t)((gw + li[b]) << 6) + lane;
+                if (FROM_LUT) {
+                    off[b] = p.lut[j];
+                } else {
+                    uint32_t ix, iy, izl;
+                    decompose(j, p.nx, p.ny, ix, iy, izl);
+                    double u, v;
+                    project_point(p.cam, p.xs[ix], p.ys[iy], p.zs[p.z0 + izl], u, v);
+                    off[b] = pixel_offset(u, v, p.H, p.W);
+                }
+            }
+        }
+        uint64_t rec[EB];
+#pragma unroll
+        for (int b = 0; b < EB; ++b) {
+            rec[b] = (uint32_t)(p.i0 + ((gw + li[b]) << 6) + lane);
+            if (off[b] >= 0 && (ALLSEEN || (p.maskbits && mask_bit(p.maskbits, off[b])))) {
+                const uint64_t px = p.frame ? (uint64_t)p.frame[off[b]] : 0ull;           // B | G<<8 | R<<16
+                rec[b] |= ((px >> 16) & 0xffull) << 32 | ((px >> 8) & 0xffull) << 40 | (px & 0xffull) << 48 | (1ull << 56);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < EB; ++b) {
+            if ((wv[b] >> lane) & 1ull) {
+                const uint64_t o = out0 + ws[b] + (uint32_t)__popcll(wv[b] & below);
+                if (o < p.capacity) p.records[o] = rec[b];
+            }
+        }
+    }
+}
+
 }  // namespace vc

@@ -170,6 +170,7 @@ struct vc_ctx {
     int refine_wl = 1;               // words per lane in the hierarchical kernel's groups: 1 or 2
     int hier_blocks_per_cu = 48;     // hierarchical kernel: oversubscribed grid, the dispatcher balances uneven groups
     int refine_pair = 1;             // hierarchical LUT kernel: two cameras per dependent round trip
+    int emit_lanes = 1;              // record expansion: lanes = voxels of a word (1) or lanes = survivors (0)
     int fused_hier = 1;              // VC_MODE_FUSED: interval-arithmetic word rejection (needs ny % 64 == 0)
     int lut_hier = 1;                // VC_MODE_LUT: hierarchical kernel (boxes + block grid) instead of stream + refine
     DevBuf<uint16_t> d_viewmask;
@@ -280,7 +281,13 @@ int launch_emit(vc_ctx *ctx, StepBuf &sb, hipStream_t st)
 {
     const EmitParams &e = sb.emit;
     const dim3 eg((e.ngroups + 3) / 4), block(kBlock);
-    if (e.lut && sb.allseen) hipLaunchKernelGGL((k_emit_words<true, true, kEmitBatch>), eg, block, 0, st, e);
+    if (ctx->emit_lanes) {
+        if (e.lut && sb.allseen) hipLaunchKernelGGL((k_emit_lanes<true, true, 8>), eg, block, 0, st, e);
+        else if (e.lut) hipLaunchKernelGGL((k_emit_lanes<true, false, 8>), eg, block, 0, st, e);
+        else if (sb.allseen) hipLaunchKernelGGL((k_emit_lanes<false, true, 4>), eg, block, 0, st, e);
+        else hipLaunchKernelGGL((k_emit_lanes<false, false, 4>), eg, block, 0, st, e);
+    }
+    else if (e.lut && sb.allseen) hipLaunchKernelGGL((k_emit_words<true, true, kEmitBatch>), eg, block, 0, st, e);
     else if (e.lut) hipLaunchKernelGGL((k_emit_words<true, false, kEmitBatch>), eg, block, 0, st, e);
     else if (sb.allseen) hipLaunchKernelGGL((k_emit_words<false, true, kEmitBatch>), eg, block, 0, st, e);
     else hipLaunchKernelGGL((k_emit_words<false, false, kEmitBatch>), eg, block, 0, st, e);
@@ -874,6 +881,7 @@ int vc_set_option(vc_ctx *ctx, const char *name, int value)
     else if (k == "reorder") ctx->reorder = value != 0;
     else if (k == "lut_hier") ctx->lut_hier = value != 0;
     else if (k == "fused_hier") ctx->fused_hier = value != 0;
+    else if (k == "emit_lanes") ctx->emit_lanes = value != 0;
     else if (k == "refine_pair") ctx->refine_pair = value != 0;
     else if (k == "refine_wl" && (value == 1 || value == 2)) ctx->refine_wl = value;
     else if (k == "hier_blocks_per_cu" && value >= 1 && value <= 4096) ctx->hier_blocks_per_cu = value;
