@@ -171,6 +171,59 @@ def test_every_kernel_family_agrees_with_oracle(eng, seed):
         eng.set_option("no_such_option", 1)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_hostile_cameras_inside_the_volume(eng, seed):
+    """Cameras INSIDE or next to the grid (depth crosses zero inside 64-voxel words, points behind the
+    camera, projections that blow up) with strong distortion: the word-rejection bounds (pixel boxes,
+    interval arithmetic) must never lose a voxel, and non-finite projections must fail the bounds test
+    exactly as on the CPU."""
+    from voxcarve.camera import Camera
+    from oracle import carve_c
+    rng = np.random.default_rng(900 + seed)
+    H, W = 96, 128
+    cams3 = []
+    for _ in range(3):
+        rvec = rng.normal(size=3)
+        rvec *= rng.uniform(0.1, 3.1) / np.linalg.norm(rvec)
+        K = np.array([[rng.uniform(30, 200), 0, W / 2], [0, rng.uniform(30, 200), H / 2], [0, 0, 1.0]])
+        dist = np.array([rng.normal(0, 0.8), rng.normal(0, 0.5), rng.normal(0, 0.05), rng.normal(0, 0.05), rng.normal(0, 0.3)])
+        cam = Camera(K, dist, rvec, np.zeros(3))
+        centre = np.array([rng.uniform(-512, 1024), rng.uniform(-1024, 1024), rng.uniform(-2048, 512)])   # inside the bounds
+        cam.tvec = -cam.R @ centre
+        cams3.append(cam)
+    masks3 = [np.where(rng.random((H, W)) < 0.7, 255, 0).astype(np.uint8) for _ in range(3)]
+    frames3 = [rng.integers(0, 256, (H, W, 3), dtype=np.uint8) for _ in range(3)]
+    grid = [(24, 64, 24), (16, 128, 12), (40, 64, 10), (9, 192, 9), (32, 64, 32), (12, 70, 12)][seed]
+    oc = fx.oracle_cams(cams3)
+    eng.set_grid(*grid)
+    eng.set_cameras(cams3, H, W)
+    eng.upload_masks(masks3)
+    eng.upload_frame(0, frames3[0])
+    eng.build_lut()
+    for mv in (3, 2):
+        want = carve_c.carve(*grid, oc, masks3, frames3, min_views=mv, color_cam=0, want_lut=True)
+        for c in range(3):
+            assert np.array_equal(eng.fetch_lut(c), want["offsets"][c])
+        for mode in ("lut", "fused"):
+            assert eng.carve(mode=mode, min_views=mv, color_cam=0) == want["count"], (mode, mv)
+            idx, rgb, _ = eng.fetch()
+            assert np.array_equal(idx, want["idx"]) and np.array_equal(rgb[:, ::-1], want["bgr"]), (mode, mv)
+    # each hostile camera alone (min_views == C == 1: the word-rejecting kernels, many survivors)
+    total = 0
+    for c in range(3):
+        eng.set_cameras([cams3[c]], H, W)
+        eng.upload_masks([masks3[c]])
+        eng.upload_frame(0, frames3[c])
+        eng.build_lut()
+        want = carve_c.carve(*grid, [oc[c]], [masks3[c]], [frames3[c]], color_cam=0)
+        total += want["count"]
+        for mode in ("lut", "fused"):
+            assert eng.carve(mode=mode, color_cam=0) == want["count"], (mode, c)
+            idx, rgb, _ = eng.fetch()
+            assert np.array_equal(idx, want["idx"]) and np.array_equal(rgb[:, ::-1], want["bgr"]), (mode, c)
+    assert total > 500
+
+
 def test_config5_shape_16_cameras_1080p(eng):
     """BASELINE config 5 inputs (16 synthetic ring cameras, 1080x1920 masks, colour on) at an
     oracle-sized grid: masks too large for the LDS path, 16-bit camera bitmask, all modes."""
