@@ -90,6 +90,12 @@ int vc_set_cameras(vc_ctx *ctx, uint32_t n_cameras, const double *K9, const doub
 /* masks: u8 [C,H,W], foreground where > 0 (line 112).  Bit-packed on the device.
  * slot selects one of the resident frame sets (0..n-1, created on first use). */
 int vc_upload_masks(vc_ctx *ctx, uint32_t slot, const uint8_t *masks);
+/* Tail of extract_foreground_mask on the device (background_subtraction.py:195-206): per camera,
+ * optional 2x2 MORPH_OPEN then 2x2 MORPH_CLOSE applied to the byte masks of every following
+ * vc_upload_masks, before the final > 0 binarisation.  Arrays of C flags, NULL = none. */
+int vc_set_mask_postfilter(vc_ctx *ctx, const uint8_t *open2x2, const uint8_t *close2x2);
+/* The device's binarised mask of one camera as u8 [H,W] in {0,255} (tests). */
+int vc_fetch_mask(vc_ctx *ctx, uint32_t slot, uint32_t cam, uint8_t *out);
 /* bgr: u8 [H,W,3] image of camera cam (0-based) for colour sampling (lines 119-122). */
 int vc_upload_frame(vc_ctx *ctx, uint32_t slot, uint32_t cam, const uint8_t *bgr);
 

@@ -252,6 +252,31 @@ def test_config5_shape_16_cameras_1080p(eng):
     assert np.array_equal(eng.fetch()[0], want12["idx"])
 
 
+def test_device_mask_postfilter_matches_restatement(eng, cams, masks):
+    """2x2 open / close + binarisation on the device == the numpy restatement, per camera flags."""
+    from oracle import postfilter_np as pf
+    rng = np.random.default_rng(5)
+    H, W = masks[0].shape
+    noisy = [np.where(rng.random((H, W)) < 0.02, 255 - m, m).astype(np.uint8) for m in masks]     # salt + pepper on the real masks
+    noisy[3] = rng.integers(0, 256, (H, W), dtype=np.uint8) * (rng.random((H, W)) < 0.5)          # grey levels too
+    eng.set_grid(32, 64, 32)
+    eng.set_cameras(cams, H, W)
+    flags_open = [True, False, True, False]
+    flags_close = [True, True, False, False]
+    eng.set_mask_postfilter(flags_open, flags_close)
+    eng.upload_masks(noisy)
+    for c in range(4):
+        want = pf.post_filter(noisy[c], flags_open[c], flags_close[c])
+        assert np.array_equal(eng.fetch_mask(c), want), c
+    n_filtered = eng.carve(color_cam=None)
+    eng.set_mask_postfilter(None, None)
+    eng.upload_masks([pf.post_filter(noisy[c], flags_open[c], flags_close[c]) for c in range(4)])
+    assert eng.carve(color_cam=None) == n_filtered
+    eng.upload_masks(noisy)
+    for c in range(4):
+        assert np.array_equal(eng.fetch_mask(c), np.where(noisy[c] > 0, 255, 0))
+
+
 def test_all_background_and_all_foreground(eng, cams, masks):
     from oracle import carve_c
     H, W = masks[0].shape

@@ -131,3 +131,27 @@ def test_index_range_slabs_concatenate(built, cams, masks, frames):
              for z0, z1 in ((0, 10), (10, 11), (11, 32))]
     assert np.array_equal(np.concatenate([p["idx"] for p in parts]), full["idx"])
     assert np.array_equal(np.concatenate([p["bgr"] for p in parts]), full["bgr"])
+
+
+def test_postfilter_restatement_small_cases():
+    """2x2 open/close with OpenCV's top-left-biased window (background_subtraction.py:195-206); unpinned vs cv2."""
+    from oracle import postfilter_np as pf
+    a = np.zeros((5, 6), np.uint8)
+    a[2, 3] = 255                                            # single pixel
+    assert np.array_equal(pf.dilate2x2(a), np.pad(np.full((2, 2), 255, np.uint8), ((2, 1), (3, 1))))
+    assert pf.erode2x2(a).sum() == 0
+    assert pf.post_filter(a, True, False).sum() == 0         # opening removes a lone pixel
+    b = np.full((5, 6), 255, np.uint8)
+    b[2, 3] = 0                                              # single hole
+    assert np.array_equal(pf.post_filter(b, False, True), np.full((5, 6), 255, np.uint8))   # closing fills it
+    assert np.array_equal(pf.erode2x2(b) == 0, np.pad(np.ones((2, 2), bool), ((2, 1), (3, 1))))
+    c = np.zeros((6, 6), np.uint8)
+    c[1:4, 1:4] = 200                                        # 3x3 square survives, binarised -- and MOVES: erode and
+    out = pf.post_filter(c, True, True)                      # dilate share the same un-reflected window, so each of
+    assert out.dtype == np.uint8 and set(np.unique(out)) <= {0, 255}   # open and close shifts it one pixel down-right
+    assert out[3:6, 3:6].all() and int((out > 0).sum()) == 9
+    edge = np.zeros((4, 4), np.uint8)
+    edge[0, :] = 255                                         # border row: outside pixels are ignored, not zero
+    assert np.array_equal(pf.erode2x2(edge)[0], [255, 255, 255, 255])
+    m = fx.golden_masks()[0]
+    assert np.array_equal(pf.post_filter(m), m)              # no flags: only the binarisation

@@ -48,7 +48,10 @@ class ReferenceVideoSource:
     Needs cv2 (opencv-contrib) and the reference's ``background_subtraction`` / ``utils`` on
     sys.path -- true when this package is used from inside a reference checkout."""
 
-    def __init__(self, data_path="data", num_cameras=4):
+    def __init__(self, data_path="data", num_cameras=4, post_on_device=False):
+        # post_on_device: leave the 2x2 open/close tail of extract_foreground_mask to the GPU
+        # (CarveEngine.set_mask_postfilter with cam_bg_model_params[c][4:6]); masks then come out unfiltered.
+        self.post_on_device = post_on_device
         import cv2  # noqa: F401  (ImportError here means: install a frame source instead)
         import background_subtraction
         import utils
@@ -69,8 +72,9 @@ class ReferenceVideoSource:
         masks = []
         for camera, frame in enumerate(frames):
             p = cam_bg_model_params[camera]
+            post = (False, False) if self.post_on_device else (p[4], p[5])
             masks.append(np.array(self._bs.extract_foreground_mask(frame, self.bg_models[camera], 0, p[0], p[1],
-                                                                   p[2], p[3], p[4], p[5])))
+                                                                   p[2], p[3], post[0], post[1])))
         return frames, masks
 
 
@@ -125,6 +129,10 @@ def set_voxel_positions(width, height, depth):
     H, W = np.asarray(masks[0]).shape[:2]
     if _engine._sized != (H, W):
         _engine.set_cameras(_engine._cameras, H, W)
+        if getattr(_source, "post_on_device", False):
+            n = _settings["num_cameras"]
+            _engine.set_mask_postfilter([cam_bg_model_params[c][4] for c in range(n)],
+                                        [cam_bg_model_params[c][5] for c in range(n)])
         if _settings["mode"] == "lut":
             _engine.build_lut()
         _engine._sized = (H, W)

@@ -96,6 +96,25 @@ __global__ __launch_bounds__(kBlock) void k_pack_masks(const uint8_t *__restrict
     bits[(size_t)c * mwords + w] = out;
 }
 
+// ---------------------------------------------------------------- mask post-filter
+// One pass of cv2.erode / cv2.dilate with the 2x2 MORPH_RECT element the reference applies after
+// contour filling (background_subtraction.py:195-203): OpenCV anchors an even element at ksize/2,
+// so the window of output (y, x) is rows y-1..y, columns x-1..x, for erosion AND dilation (no
+// reflection), and pixels outside the image are ignored (morphologyDefaultBorderValue).
+template <bool DILATE>
+__global__ __launch_bounds__(kBlock) void k_morph2x2(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+                                                     uint32_t H, uint32_t W)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= H * W) return;
+    const uint32_t y = i / W, x = i - y * W;
+    uint32_t v = in[i];
+    if (x > 0) { const uint32_t o = in[i - 1]; v = DILATE ? (o > v ? o : v) : (o < v ? o : v); }
+    if (y > 0) { const uint32_t o = in[i - W]; v = DILATE ? (o > v ? o : v) : (o < v ? o : v); }
+    if (x > 0 && y > 0) { const uint32_t o = in[i - W - 1]; v = DILATE ? (o > v ? o : v) : (o < v ? o : v); }
+    out[i] = (uint8_t)v;
+}
+
 // ---------------------------------------------------------------- camera selectivity
 // Pass count of each camera on `nsamples` evenly spaced voxels of the slab: the host
 // sorts cameras by it so the carve visits the most selective camera first.  Changes

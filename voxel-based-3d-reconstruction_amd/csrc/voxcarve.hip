@@ -151,6 +151,8 @@ struct vc_ctx {
     bool have_cams = false;
 
     std::vector<Slot> slots;
+    uint8_t post_open[VC_MAX_CAMERAS] = {0}, post_close[VC_MAX_CAMERAS] = {0};   // 2x2 open / close per camera
+    DevBuf<uint8_t> d_morph;         // ping-pong image for the post-filter
     DevBuf<uint8_t> d_stage;         // H2D staging for byte masks
 
     DevBuf<int32_t> d_lut;
@@ -365,7 +367,7 @@ int vc_destroy(vc_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
     for (Slot &s : ctx->slots) { release(s.bits); release(s.frames); release(s.grid); }
-    release(ctx->d_axes); release(ctx->d_stage); release(ctx->d_lut); release(ctx->d_bbox);
+    release(ctx->d_axes); release(ctx->d_stage); release(ctx->d_morph); release(ctx->d_lut); release(ctx->d_bbox);
     for (StepBuf &b : ctx->sb) {
         release(b.words); release(b.groupcnt); release(b.groupoff); release(b.blocksum); release(b.blockoff); release(b.records);
         if (b.h_total) (void)hipHostFree(b.h_total);
@@ -483,6 +485,22 @@ int vc_upload_masks(vc_ctx *ctx, uint32_t slot, const uint8_t *masks)
     VC_TRY(ensure(ctx, s->bits, (size_t)ctx->mwords * ctx->C));
     VC_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     VC_HIP(ctx, hipMemcpyAsync(ctx->d_stage.ptr, masks, HW * ctx->C, hipMemcpyHostToDevice, ctx->stream));
+    for (uint32_t c = 0; c < ctx->C; ++c) {
+        if (!ctx->post_open[c] && !ctx->post_close[c]) continue;
+        // MORPH_OPEN = erode, dilate; MORPH_CLOSE = dilate, erode (opening first when both are set)
+        VC_TRY(ensure(ctx, ctx->d_morph, HW));
+        uint8_t *img = ctx->d_stage.ptr + HW * c, *tmp = ctx->d_morph.ptr;
+        const dim3 mg(grid_for(HW)), mb(kBlock);
+        if (ctx->post_open[c]) {
+            hipLaunchKernelGGL((k_morph2x2<false>), mg, mb, 0, ctx->stream, img, tmp, ctx->H, ctx->W);
+            hipLaunchKernelGGL((k_morph2x2<true>), mg, mb, 0, ctx->stream, tmp, img, ctx->H, ctx->W);
+        }
+        if (ctx->post_close[c]) {
+            hipLaunchKernelGGL((k_morph2x2<true>), mg, mb, 0, ctx->stream, img, tmp, ctx->H, ctx->W);
+            hipLaunchKernelGGL((k_morph2x2<false>), mg, mb, 0, ctx->stream, tmp, img, ctx->H, ctx->W);
+        }
+        VC_HIP(ctx, hipGetLastError());
+    }
     dim3 grid((ctx->mwords + kBlock - 1) / kBlock, ctx->C);
     hipLaunchKernelGGL(k_pack_masks, grid, dim3(kBlock), 0, ctx->stream, ctx->d_stage.ptr, s->bits.ptr,
                        ctx->C, (uint32_t)HW, ctx->mwords);
@@ -502,6 +520,31 @@ int vc_upload_masks(vc_ctx *ctx, uint32_t slot, const uint8_t *masks)
     VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.h2d_ms, ctx->ev[0], ctx->ev[1]));
     s->have_masks = true;
     s->order_valid = false;
+    return VC_OK;
+}
+
+int vc_set_mask_postfilter(vc_ctx *ctx, const uint8_t *open2x2, const uint8_t *close2x2)
+{
+    if (!ctx) return VC_ERR_ARG;
+    if (!ctx->have_cams) return fail(ctx, VC_ERR_ARG, "vc_set_cameras must precede vc_set_mask_postfilter");
+    for (uint32_t c = 0; c < VC_MAX_CAMERAS; ++c) {
+        ctx->post_open[c] = (open2x2 && c < ctx->C) ? (open2x2[c] != 0) : 0;
+        ctx->post_close[c] = (close2x2 && c < ctx->C) ? (close2x2[c] != 0) : 0;
+    }
+    return VC_OK;
+}
+
+int vc_fetch_mask(vc_ctx *ctx, uint32_t slot, uint32_t cam, uint8_t *out)
+{
+    if (!ctx || !out) return VC_ERR_ARG;
+    if (slot >= ctx->slots.size() || !ctx->slots[slot].have_masks) return fail(ctx, VC_ERR_ARG, "no masks uploaded in slot %u", slot);
+    if (cam >= ctx->C) return fail(ctx, VC_ERR_ARG, "camera %u not in [0,%u)", cam, ctx->C);
+    VC_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<uint32_t> bits(ctx->mwords);
+    VC_HIP(ctx, hipMemcpy(bits.data(), ctx->slots[slot].bits.ptr + (size_t)cam * ctx->mwords, sizeof(uint32_t) * ctx->mwords,
+                          hipMemcpyDeviceToHost));
+    const size_t HW = (size_t)ctx->H * ctx->W;
+    for (size_t p = 0; p < HW; ++p) out[p] = ((bits[p >> 5] >> (p & 31)) & 1u) ? 255 : 0;
     return VC_OK;
 }
 

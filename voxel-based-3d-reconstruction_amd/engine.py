@@ -106,6 +106,25 @@ class CarveEngine:
             raise ValueError("masks shape %s, expected %s" % (m.shape, (self.n_cameras,) + self.image_size))
         self._check(self._L.vc_upload_masks(self._ctx, slot, _ptr(m, ctypes.c_uint8)), "vc_upload_masks")
 
+    def set_mask_postfilter(self, open2x2=None, close2x2=None):
+        """Per-camera 2x2 MORPH_OPEN / MORPH_CLOSE applied on the device to every following
+        upload_masks (tail of the reference's extract_foreground_mask, background_subtraction.py:195-206)."""
+        def arr(flags):
+            if flags is None:
+                return None
+            a = np.ascontiguousarray([1 if f else 0 for f in flags], dtype=np.uint8)
+            if a.size != self.n_cameras:
+                raise ValueError("need one flag per camera")
+            return a
+        o, c = arr(open2x2), arr(close2x2)
+        self._check(self._L.vc_set_mask_postfilter(self._ctx, _ptr(o, ctypes.c_uint8) if o is not None else None,
+                                                   _ptr(c, ctypes.c_uint8) if c is not None else None), "vc_set_mask_postfilter")
+
+    def fetch_mask(self, cam, slot=0):
+        out = np.empty(self.image_size, dtype=np.uint8)
+        self._check(self._L.vc_fetch_mask(self._ctx, slot, cam, _ptr(out, ctypes.c_uint8)), "vc_fetch_mask")
+        return out
+
     def upload_frame(self, cam, bgr, slot=0):
         f = np.ascontiguousarray(bgr, dtype=np.uint8)
         if f.shape != self.image_size + (3,):
