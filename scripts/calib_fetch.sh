@@ -1,5 +1,6 @@
 # Calibrates FETCH_SIZE on known byte counts: 17.18 GB streamed with dword and dwordx4 loads.
 OUT=$GRAFT_REPO_ROOT/gpurun_out/calib; mkdir -p $OUT
+[ -x $GRAFT_REPO_ROOT/scripts/micro/stream ] || hipcc --offload-arch=gfx950 -O3 -o $GRAFT_REPO_ROOT/scripts/micro/stream $GRAFT_REPO_ROOT/scripts/micro/stream.hip
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- $GRAFT_REPO_ROOT/scripts/micro/stream > $OUT/fetch.log 2>&1
 python3 - <<PY

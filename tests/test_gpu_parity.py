@@ -462,3 +462,33 @@ def test_full_size_1024_properties(eng, cams, masks, frames):
     i0 = 256 * 1024 * 1024
     sel = (idx >= i0) & (idx < 2 * i0)
     assert np.array_equal(ra, rec[sel])
+
+
+def test_index_width_at_the_u32_limit(eng, cams, masks, frames):
+    """2048 x 2048 x 1023 = 4 290 772 992 voxels, 4 million short of 2^32: every index computation
+    that could wrap does so here.  Table-free mode (a table for this grid would be 17 GB per camera);
+    two thin oracle slabs, one of them the last layers, pin the values."""
+    from oracle import carve_c
+    from voxcarve._lib import VoxcarveError
+    grid = (2048, 2048, 1023)
+    setup_real(eng, cams, masks, frames, grid)
+    n = eng.carve(mode="fused")
+    rec = eng.fetch_records(pinned=True)
+    idx = rec.astype(np.uint32)
+    assert n == rec.size and n > 100_000_000
+    assert np.all(idx[1:] > idx[:-1])
+    layer = 2048 * 2048
+    for z0 in (500, 1021):
+        i0, i1 = z0 * layer, (z0 + 2) * layer
+        want = carve_c.carve(*grid, fx.oracle_cams(cams), masks, frames, index_range=(i0, i1))
+        lo, hi = np.searchsorted(idx, [i0, min(i1, 2 ** 32 - 1)])
+        if i1 >= 2 ** 32:
+            hi = idx.size
+        assert np.array_equal(idx[lo:hi], want["idx"])
+        assert np.array_equal(rec[lo:hi].view(np.uint8).reshape(-1, 8)[:, 4:7][:, ::-1], want["bgr"])
+    eng.set_slab(1000, 1023)                                   # a slab that ends at the last voxel
+    m = eng.carve(mode="fused")
+    tail = eng.fetch_records()
+    assert m == int((idx >= 1000 * layer).sum()) and np.array_equal(tail, rec[idx >= 1000 * layer])
+    with pytest.raises(VoxcarveError):
+        eng.set_grid(2048, 2048, 1024)                         # 2^32 voxels: refused
