@@ -353,7 +353,7 @@ int vc_create(int device, vc_ctx **out)
     ctx->force_generic = fg && fg[0] == '1';
     if (e1 != hipSuccess) {
         int rc = fail(nullptr, VC_ERR_HIP, "context setup: %s", hipGetErrorString(e1));
-        delete ctx;
+        vc_destroy(ctx);                 // releases whatever was created so far
         return rc;
     }
     *out = ctx;
@@ -399,6 +399,7 @@ int vc_synchronize(vc_ctx *ctx)
 int vc_set_grid(vc_ctx *ctx, uint32_t nx, uint32_t ny, uint32_t nz, const double bounds[6])
 {
     if (!ctx || !bounds) return VC_ERR_ARG;
+    if (ctx->npending) return fail(ctx, VC_ERR_ARG, "carve steps are in flight: collect them with vc_carve_end first");
     if (nx == 0 || ny == 0 || nz == 0) return fail(ctx, VC_ERR_ARG, "grid dimensions must be >= 1");
     const uint64_t N = (uint64_t)nx * ny * nz;
     if (N > 0xffffffffull || (uint64_t)nx * ny > 0xffffffffull)
@@ -422,6 +423,7 @@ int vc_set_grid(vc_ctx *ctx, uint32_t nx, uint32_t ny, uint32_t nz, const double
 int vc_set_slab(vc_ctx *ctx, uint32_t z0, uint32_t z1)
 {
     if (!ctx) return VC_ERR_ARG;
+    if (ctx->npending) return fail(ctx, VC_ERR_ARG, "carve steps are in flight: collect them with vc_carve_end first");
     if (!ctx->have_grid) return fail(ctx, VC_ERR_ARG, "vc_set_grid must precede vc_set_slab");
     if (z0 > z1 || z1 > ctx->nz) return fail(ctx, VC_ERR_ARG, "slab [%u,%u) outside [0,%u]", z0, z1, ctx->nz);
     ctx->z0 = z0; ctx->z1 = z1;
@@ -443,6 +445,7 @@ int vc_set_cameras(vc_ctx *ctx, uint32_t C, const double *K9, const double *dist
                    const double *t3, uint32_t H, uint32_t W)
 {
     if (!ctx || !K9 || !dist5 || !R9 || !t3) return VC_ERR_ARG;
+    if (ctx->npending) return fail(ctx, VC_ERR_ARG, "carve steps are in flight: collect them with vc_carve_end first");
     if (C == 0 || C > VC_MAX_CAMERAS) return fail(ctx, VC_ERR_ARG, "camera count %u not in [1,%d]", C, VC_MAX_CAMERAS);
     if (H == 0 || W == 0 || (uint64_t)H * W > 0x7fffffffull) return fail(ctx, VC_ERR_ARG, "bad mask size %ux%u", H, W);
     for (uint32_t c = 0; c < C; ++c) {
@@ -570,6 +573,7 @@ int vc_upload_frame(vc_ctx *ctx, uint32_t slot, uint32_t cam, const uint8_t *bgr
 int vc_build_lut(vc_ctx *ctx)
 {
     if (!ctx) return VC_ERR_ARG;
+    if (ctx->npending) return fail(ctx, VC_ERR_ARG, "carve steps are in flight: collect them with vc_carve_end first");
     if (!ctx->have_grid || !ctx->have_cams) return fail(ctx, VC_ERR_ARG, "grid and cameras must be set before vc_build_lut");
     VC_HIP(ctx, hipSetDevice(ctx->device));
     const uint64_t n = ctx->n_voxels();
