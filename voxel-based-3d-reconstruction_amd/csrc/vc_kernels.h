@@ -730,8 +730,11 @@ __global__ __launch_bounds__(kBlock) void k_count_groups(const uint64_t *__restr
 }
 
 // Level 1: exclusive scan of the group counts inside blocks of kScanBlock groups.
+// A single-block launch (<= 1024 groups: grids up to 4 M voxels) also finishes level 2 itself.
+// The grand total goes to device memory AND straight to a page-locked host word (no copy kernel).
 __global__ __launch_bounds__(kScanBlock) void k_scan_groups(const uint32_t *__restrict__ cnt, uint32_t ngroups,
-                                                            uint32_t *__restrict__ off, uint64_t *__restrict__ blocksum)
+                                                            uint32_t *__restrict__ off, uint64_t *__restrict__ blocksum,
+                                                            uint64_t *__restrict__ blockoff, uint64_t *__restrict__ total_host)
 {
     __shared__ uint32_t wsum[kScanBlock / 64];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
@@ -748,12 +751,19 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_groups(const uint32_t *__re
         total += s;
     }
     if (i < ngroups) off[i] = before + incl - c;
-    if (t == 0) blocksum[blockIdx.x] = total;
+    if (t == 0) {
+        blocksum[blockIdx.x] = total;
+        if (gridDim.x == 1) {
+            blockoff[0] = 0;
+            blockoff[1] = total;
+            *total_host = total;
+        }
+    }
 }
 
 // Level 2: exclusive scan of the (at most kScanBlock) block sums; blockoff[nblocks] = total.
 __global__ __launch_bounds__(kScanBlock) void k_scan_blocks(const uint64_t *__restrict__ blocksum, uint32_t nblocks,
-                                                            uint64_t *__restrict__ blockoff)
+                                                            uint64_t *__restrict__ blockoff, uint64_t *__restrict__ total_host)
 {
     __shared__ uint64_t wsum[kScanBlock / 64];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
@@ -774,7 +784,10 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_blocks(const uint64_t *__re
         total += s;
     }
     if (t < nblocks) blockoff[t] = before + incl - c;
-    if (t == 0) blockoff[nblocks] = total;
+    if (t == 0) {
+        blockoff[nblocks] = total;
+        *total_host = total;
+    }
 }
 
 // BGR bytes -> one BGRX dword per pixel, so a colour sample is a single aligned load.

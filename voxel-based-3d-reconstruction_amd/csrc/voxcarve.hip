@@ -767,11 +767,12 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
         VC_HIP(ctx, hipGetLastError());
     }
     hipLaunchKernelGGL(k_scan_groups, dim3(nscan), dim3(kScanBlock), 0, s2, sb.groupcnt.ptr, ngroups, sb.groupoff.ptr,
-                       sb.blocksum.ptr);
+                       sb.blocksum.ptr, sb.blockoff.ptr, sb.h_total);
     VC_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(kScanBlock), 0, s2, sb.blocksum.ptr, nscan, sb.blockoff.ptr);
-    VC_HIP(ctx, hipGetLastError());
-    VC_HIP(ctx, hipMemcpyAsync(sb.h_total, sb.blockoff.ptr + nscan, sizeof(uint64_t), hipMemcpyDeviceToHost, s2));
+    if (nscan > 1) {
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(kScanBlock), 0, s2, sb.blocksum.ptr, nscan, sb.blockoff.ptr, sb.h_total);
+        VC_HIP(ctx, hipGetLastError());
+    }
 
     EmitParams &e = sb.emit;
     memset(&e, 0, sizeof e);
