@@ -42,12 +42,12 @@ N_SLOTS = 4
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--grid", type=int, default=1024)
     ap.add_argument("--mode", choices=("lut", "lut_stream", "fused"), default="lut")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--prewarm-seconds", type=float, default=1.0,
                     help="untimed launches before the W warm-up steps so the clocks have ramped (a cold device ran "
                          "the same kernels up to 19 %% slower)")
@@ -155,14 +155,15 @@ def run_mode(eng, grp, mode, steps, warmup, multi, host_transport=None, depth=2)
 
 
 def cpu_baseline(grid, cams, masks, frames, seconds):
-    """The C/OpenMP oracle ("port") on this host's cores, on a z-slab sample of the same grid."""
+    """The C/OpenMP oracle ("port") on this host's cores: the WHOLE grid of the same workload when that
+    fits the time budget (a few seconds on a many-core host), else a centred z-slab sized to it."""
     import fixtures_util as fx
     from oracle import carve_c
     oc = fx.oracle_cams(cams)
     threads = len(os.sched_getaffinity(0))
     layer = grid * grid
-    carve_c.carve(grid, grid, grid, oc, masks, frames, index_range=(0, layer * 2), threads=threads, cap=1 << 22)
-    probe = max(1, min(grid, 8))
+    carve_c.carve(grid, grid, grid, oc, masks, frames, index_range=(0, layer * 2), threads=threads, cap=1 << 22)   # warm the pool
+    probe = max(1, min(grid, 16))
     z_mid = grid // 2
     t0 = time.perf_counter()
     carve_c.carve(grid, grid, grid, oc, masks, frames, index_range=(z_mid * layer, (z_mid + probe) * layer),
@@ -175,9 +176,10 @@ def cpu_baseline(grid, cams, masks, frames, seconds):
                         threads=threads, cap=1 << 26)
     dt = time.perf_counter() - t0
     vv = layers * layer * len(cams)
+    what = "the whole %d^3 grid" % grid if layers == grid else "z-layers [%d,%d) of the %d^3 grid" % (z0, z0 + layers, grid)
     return {"value": round(vv / dt / 1e6, 2), "unit": "Mvoxel-views/s", "cores": threads, "kind": "port",
-            "sample": "oracle/carve_ref.c (C/OpenMP, -O2 -ffp-contract=off), z-layers [%d,%d) of the %d^3 grid, "
-                      "%.3g voxel-views in %.2f s, %d survivors" % (z0, z0 + layers, grid, vv, dt, res["count"])}
+            "sample": "oracle/carve_ref.c (C/OpenMP, -O2 -ffp-contract=off), %s, %.3g voxel-views in %.2f s, "
+                      "%d survivors" % (what, vv, dt, res["count"])}
 
 
 def main():
@@ -213,6 +215,7 @@ def main():
         grp.attach(eng)
         grp.barrier()
         slabs.file_rendezvous_cleanup(grp.rank)
+    prep_ms = eng.timing()["h2d_ms"]          # last frame set: H2D of the byte masks + post-filter + bit-pack + block grid
     eng.build_lut()
     lut_ms = eng.timing()["lut_ms"]
 
@@ -301,7 +304,8 @@ def main():
         "roofline_stream": roof_stream,
         "other_modes": others,
         "phases_ms": {"carve_kernels": round(head["kernel_ms"], 4), "compact": round(head["compact_ms"], 4),
-                      "gather": round(head["gather_ms"], 4), "lut_build_once": round(lut_ms, 3)},
+                      "gather": round(head["gather_ms"], 4), "lut_build_once": round(lut_ms, 3),
+                      "frame_set_upload_and_prep": round(prep_ms, 4)},
     }
     if args.e2e and grp.world == 1:
         # PCIe-inclusive rate (never `value`): byte masks + colour frame up, carve, records down, per step.
