@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--transport", choices=("rccl", "host"), default="rccl",
                     help="N>1 survivor exchange: rccl (device, default) or host (gloo; rehearsal on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0")
+    ap.add_argument("--force-comm", action="store_true",
+                    help="rehearsal: take the N > 1 path (file rendezvous, RCCL communicator, all-gather per step) even with one rank")
     ap.add_argument("--e2e", action="store_true", help="also time host->device inputs + device->host records per step")
     return ap.parse_args()
 
@@ -91,7 +93,7 @@ class Group:
     def barrier(self):
         if self.dist:
             self.dist.barrier()
-        elif self.eng is not None and self.world > 1:
+        elif self.eng is not None:
             self.eng.comm_max(0.0)
 
     def max(self, x):
@@ -100,7 +102,7 @@ class Group:
             t = torch.tensor([x], dtype=torch.float64)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             return float(t.item())
-        if self.eng is not None and self.world > 1:
+        if self.eng is not None:
             return self.eng.comm_max(x)
         return x
 
@@ -205,7 +207,7 @@ def main():
     for s in range(N_SLOTS):
         eng.upload_masks([np.roll(m, 3 * s, axis=1) for m in masks], slot=s)
         eng.upload_frame(1, np.roll(frames[1], 3 * s, axis=1), slot=s)
-    multi = grp.world > 1
+    multi = grp.world > 1 or args.force_comm
     host_transport = None
     if multi and args.transport == "host":
         host_transport = slabs.TorchTransport()
