@@ -80,6 +80,7 @@ class Group:
             raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (self.world, n_gpus))
         self.dist = None
         self.eng = None
+        self.shm = None
         if self.world > 1 and use_torch:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             import torch.distributed as dist
@@ -90,9 +91,15 @@ class Group:
         """From here on barriers and reductions run over the engine's RCCL communicator."""
         self.eng = eng
 
+    def attach_fallback(self, transport):
+        """RCCL unavailable: barriers and reductions through the /dev/shm exchange."""
+        self.shm = transport
+
     def barrier(self):
         if self.dist:
             self.dist.barrier()
+        elif self.shm is not None:
+            self.shm.barrier()
         elif self.eng is not None:
             self.eng.comm_max(0.0)
 
@@ -102,6 +109,8 @@ class Group:
             t = torch.tensor([x], dtype=torch.float64)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             return float(t.item())
+        if self.shm is not None:
+            return self.shm.max(x)
         if self.eng is not None:
             return self.eng.comm_max(x)
         return x
@@ -109,6 +118,8 @@ class Group:
     def close(self):
         if self.dist:
             self.dist.destroy_process_group()
+        if self.shm is not None:
+            self.shm.close()
 
 
 def run_mode(eng, grp, mode, steps, warmup, multi, host_transport=None, depth=2):
@@ -119,7 +130,7 @@ def run_mode(eng, grp, mode, steps, warmup, multi, host_transport=None, depth=2)
     def finish():
         n = eng.carve_end()
         if multi and host_transport is not None:
-            _, total = host_transport.allgather_records(eng.fetch_records())
+            _, total = host_transport.allgather_records(eng.fetch_records(pinned=True))
             return n, total
         if multi:
             _, total = eng.allgather()
@@ -209,14 +220,22 @@ def main():
         eng.upload_frame(1, np.roll(frames[1], 3 * s, axis=1), slot=s)
     multi = grp.world > 1 or args.force_comm
     host_transport = None
+    transport_note = "rccl" if multi else "none (one rank)"
     if multi and args.transport == "host":
         host_transport = slabs.TorchTransport()
+        transport_note = "host (gloo) rehearsal"
     elif multi:
-        uid = slabs.file_rendezvous(grp.rank, voxcarve.CarveEngine.comm_unique_id() if grp.rank == 0 else None)
-        eng.comm_init(grp.world, grp.rank, uid)
-        grp.attach(eng)
-        grp.barrier()
-        slabs.file_rendezvous_cleanup(grp.rank)
+        try:
+            uid = slabs.file_rendezvous(grp.rank, voxcarve.CarveEngine.comm_unique_id() if grp.rank == 0 else None)
+            eng.comm_init(grp.world, grp.rank, uid)
+            grp.attach(eng)
+            grp.barrier()
+            slabs.file_rendezvous_cleanup(grp.rank)
+        except Exception as exc:      # no communicator: say so and still deliver a (slow) measured exchange
+            transport_note = "shm-fallback: RCCL communicator unavailable (%s)" % str(exc)[:200]
+            sys.stderr.write("[bench rank %d] %s\n" % (grp.rank, transport_note))
+            host_transport = slabs.ShmTransport(grp.world, grp.rank)
+            grp.attach_fallback(host_transport)
     prep_ms = eng.timing()["h2d_ms"]          # last frame set: H2D of the byte masks + post-filter + bit-pack + block grid
     eng.build_lut()
     lut_ms = eng.timing()["lut_ms"]
@@ -299,9 +318,9 @@ def main():
         "data": "reference calibration (4x config.xml) + frame-0 MOG mask fixtures rolled per step; synthetic colour frames",
         "config": {"workload": "%d^3 voxel grid x %d cams (%dx%d masks), z-slab split over %d GPU(s), mode=%s, "
                                "ordered survivor list + colour%s" % (G, C, W, H, grp.world, args.mode,
-                                                                     (" + RCCL all-gather" if host_transport is None else " + host (gloo) gather") if multi else ""),
+                                                                     (" + RCCL all-gather" if host_transport is None else " + host-side gather") if multi else ""),
                    "grid": [G, G, G], "cameras": C, "mode": args.mode, "survivors": head["survivors"],
-                   "steps_in_flight": args.depth},
+                   "steps_in_flight": args.depth, "exchange": transport_note},
         "roofline": roof,
         "roofline_stream": roof_stream,
         "other_modes": others,

@@ -58,3 +58,30 @@ def test_slab_split_allgather_equals_single_rank(built, tmp_path, world, grid):
         assert int(np.load(tmp_path / ("counts_%d.npy" % r)).sum()) == full["count"]
     idx, rgb, seen = unpack_records(first)
     assert np.array_equal(idx, full["idx"]) and np.array_equal(rgb[:, ::-1], full["bgr"]) and seen.all()
+
+
+def _shm_worker(rank, world, port, out_dir):
+    os.environ["MASTER_PORT"] = str(port)
+    from voxcarve import slabs
+    tr = slabs.ShmTransport(world, rank)
+    try:
+        for rnd in range(3):
+            local = (np.arange(5 + rank + rnd, dtype=np.uint64) + 1000 * rank + 1)
+            counts, total = tr.allgather_records(local)
+            assert counts.tolist() == [5 + r + rnd for r in range(world)] and total == int(counts.sum())
+            got = tr.fetch()
+            want = np.concatenate([np.arange(5 + r + rnd, dtype=np.uint64) + 1000 * r + 1 for r in range(world)])
+            assert np.array_equal(got, want)
+        assert tr.max(float(rank)) == float(world - 1)
+        tr.barrier()
+        np.save(os.path.join(out_dir, "ok_%d.npy" % rank), np.array([1]))
+    finally:
+        tr.close()
+
+
+def test_shm_fallback_transport(tmp_path):
+    """The /dev/shm exchange bench.py falls back to when no RCCL communicator can be made."""
+    import torch.multiprocessing as mp
+    world = 3
+    mp.spawn(_shm_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / ("ok_%d.npy" % r)).exists() for r in range(world))

@@ -122,6 +122,90 @@ def file_rendezvous_cleanup(rank):
                       ignore_errors=True)
 
 
+class ShmTransport:
+    """Last-resort exchange through /dev/shm files (one node): every rank writes its records, waits for
+    the others' files, reads them in rank order.  Slow (device -> host -> shared memory -> host) but free
+    of any library; bench.py falls back to it only if the RCCL communicator cannot be created, and says so."""
+
+    def __init__(self, n_ranks, rank):
+        import os
+        self.n_ranks, self.rank = n_ranks, rank
+        self.dir = os.path.join("/dev/shm", "voxcarve_xchg_%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0")))
+        os.makedirs(self.dir, exist_ok=True)
+        self.round = 0
+        self._gathered = None
+
+    def _path(self, rnd, r, kind):
+        import os
+        return os.path.join(self.dir, "%s_%d_%d.npy" % (kind, rnd, r))
+
+    def _wait(self, path, timeout=120.0):
+        import os
+        import time
+        t_end = time.time() + timeout
+        while not os.path.exists(path):
+            if time.time() > t_end:
+                raise TimeoutError("exchange file %s did not appear" % path)
+            time.sleep(0.0005)
+
+    def allgather_records(self, local_records):
+        import os
+        rnd = self.round
+        self.round += 1
+        local = np.ascontiguousarray(local_records, dtype=np.uint64)
+        tmp = self._path(rnd, self.rank, "tmp")
+        np.save(tmp, local)
+        os.replace(tmp, self._path(rnd, self.rank, "rec"))
+        parts = []
+        for r in range(self.n_ranks):
+            path = self._path(rnd, r, "rec")
+            self._wait(path)
+            parts.append(local if r == self.rank else np.load(path))
+        self._gathered = merge_rank_lists(parts)
+        # everyone has read round rnd once all ranks have posted their "done" marker; then remove own file
+        open(self._path(rnd, self.rank, "done"), "w").close()
+        for r in range(self.n_ranks):
+            self._wait(self._path(rnd, r, "done"))
+        if rnd >= 1:                                        # files of the round before are no longer needed by anyone
+            for kind in ("rec", "done"):
+                try:
+                    os.remove(self._path(rnd - 1, self.rank, kind))
+                except OSError:
+                    pass
+        counts = np.array([p.size for p in parts], dtype=np.uint64)
+        return counts, int(counts.sum())
+
+    def barrier(self):
+        self.allgather_records(np.empty(0, np.uint64))
+
+    def max(self, x):
+        import os
+        rnd = self.round
+        self.round += 1
+        tmp = self._path(rnd, self.rank, "tmpv")
+        np.save(tmp, np.array([x], dtype=np.float64))
+        os.replace(tmp, self._path(rnd, self.rank, "val"))
+        vals = []
+        for r in range(self.n_ranks):
+            path = self._path(rnd, r, "val")
+            self._wait(path)
+            vals.append(float(np.load(path)[0]))
+        return max(vals)
+
+    def fetch(self):
+        return self._gathered
+
+    def close(self):
+        """Collective: every rank says goodbye; rank 0 removes the directory once all have."""
+        import os
+        import shutil
+        open(os.path.join(self.dir, "bye_%d" % self.rank), "w").close()
+        if self.rank == 0:
+            for r in range(self.n_ranks):
+                self._wait(os.path.join(self.dir, "bye_%d" % r))
+            shutil.rmtree(self.dir, ignore_errors=True)
+
+
 def carve_slab(engine, grid, n_ranks, rank, **carve_kwargs):
     """Restrict ``engine`` to rank's slab and carve it; returns the local survivor count."""
     z0, z1 = slab_range(grid[2], n_ranks, rank)
