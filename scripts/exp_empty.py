@@ -13,11 +13,11 @@ eng.upload_masks(masks, slot=1)
 eng.upload_frame(1, frames[1], slot=0); eng.upload_frame(1, frames[1], slot=1)
 eng.build_lut()
 for slot, name in ((0, "all-background"), (1, "real masks")):
-    for hier in (1, 0):
+    for mode, hier in (("lut", 1), ("lut", 0), ("fused", 1)):
         eng.set_option("lut_hier", hier)
         ts = []
         for it in range(6):
-            n = eng.carve(slot=slot, mode="lut")
+            n = eng.carve(slot=slot, mode=mode)
             t = eng.timing(); ts.append((t["carve_ms"], t["compact_ms"]))
         a = np.array(ts[1:])
-        print(name, "hier", hier, "survivors", n, "carve med %.4f compact med %.4f" % (np.median(a[:, 0]), np.median(a[:, 1])), flush=True)
+        print(name, mode, "hier", hier, "survivors", n, "carve med %.4f compact med %.4f" % (np.median(a[:, 0]), np.median(a[:, 1])), flush=True)

@@ -15,10 +15,10 @@ if mode == "lut":
     eng.build_lut()
 if mode == "lut":
     variants = [dict(lut_hier=0)]
-    variants += [dict(lut_hier=1, emit_lanes=el) for el in (0, 1)]
+    variants += [dict(lut_hier=1, refine_pair=pr, refine_b=rb, hier_blocks_per_cu=rc) for (pr, rb) in ((1, 8),) for rc in (12, 16, 24, 32, 48, 96)]
 else:
     variants = [dict(fused_hier=0)] + [dict(fused_hier=1, hier_blocks_per_cu=b) for b in (8, 24, 48, 96)]
-defaults = dict(first_kv=1, first_blocks_per_cu=3, refine_b=8, refine_blocks_per_cu=8, fused_blocks_per_cu=8, lut_hier=1, refine_wl=1, fused_hier=1, hier_blocks_per_cu=48, refine_pair=1, emit_lanes=1)
+defaults = dict(first_kv=1, first_blocks_per_cu=3, refine_b=8, refine_blocks_per_cu=8, fused_blocks_per_cu=8, lut_hier=1, fused_hier=1, hier_blocks_per_cu=48, refine_pair=1, emit_lanes=1)
 res = {i: [] for i in range(len(variants))}
 for rnd in range(5):
     for i, v in enumerate(variants):

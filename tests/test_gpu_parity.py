@@ -154,7 +154,7 @@ def test_every_kernel_family_agrees_with_oracle(eng, seed):
     eng.upload_frame(2, frames3[2])
     eng.build_lut()
     try:
-        for opts in ({"lut_hier": 1}, {"lut_hier": 0}, {"lut_hier": 0, "first_kv": 4}, {"lut_hier": 1, "refine_b": 16, "refine_wl": 2},
+        for opts in ({"lut_hier": 1}, {"lut_hier": 0}, {"lut_hier": 0, "first_kv": 4}, {"lut_hier": 1, "refine_b": 16, "refine_pair": 0},
                      {"reorder": 0}, {"fused_hier": 0}, {"refine_pair": 0}, {"emit_lanes": 0}, {"force_generic": 1}):
             for k, v in opts.items():
                 eng.set_option(k, v)
@@ -163,9 +163,9 @@ def test_every_kernel_family_agrees_with_oracle(eng, seed):
                 idx, rgb, seen = eng.fetch()
                 assert np.array_equal(idx, want["idx"]) and np.array_equal(rgb[:, ::-1], want["bgr"]) and seen.all(), (opts, mode)
             for k in opts:
-                eng.set_option(k, {"lut_hier": 1, "first_kv": 1, "refine_b": 8, "refine_wl": 1, "reorder": 1, "fused_hier": 1, "refine_pair": 1, "emit_lanes": 1, "force_generic": 0}[k])
+                eng.set_option(k, {"lut_hier": 1, "first_kv": 1, "refine_b": 8, "reorder": 1, "fused_hier": 1, "refine_pair": 1, "emit_lanes": 1, "force_generic": 0}[k])
     finally:
-        for k, v in {"lut_hier": 1, "first_kv": 1, "refine_b": 8, "refine_wl": 1, "reorder": 1, "fused_hier": 1, "refine_pair": 1, "emit_lanes": 1, "force_generic": 0}.items():
+        for k, v in {"lut_hier": 1, "first_kv": 1, "refine_b": 8, "reorder": 1, "fused_hier": 1, "refine_pair": 1, "emit_lanes": 1, "force_generic": 0}.items():
             eng.set_option(k, v)
     with pytest.raises(Exception):
         eng.set_option("no_such_option", 1)

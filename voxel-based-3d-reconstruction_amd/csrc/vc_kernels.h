@@ -24,7 +24,7 @@ struct CarveParams {
     const uint32_t *maskbits;   // [C][mwords] of the active frame set
     const int32_t *lut;         // [C][n_pad]
     const uint64_t *bbox;       // [C][n_pad/64] pixel bounding box of each 64-voxel word (u16 u0,v0,u1,v1)
-    const uint32_t *blockgrid;  // [C][gh][gws] "any foreground in this 2^gshift-pixel block" bits of the frame set
+    const uint32_t *blockgrid;  // [2][C][gh][gws] per 2^gshift-pixel block: "any pixel foreground", then "every pixel foreground"
     uint32_t gshift, gws, gh;   // block-grid geometry
     uint64_t *words;
     uint32_t *groupcnt;         // survivors per group of 64 words (kernels that know it write it)
@@ -265,120 +265,115 @@ __global__ __launch_bounds__(kFirstBlock) void k_lut_first(const CarveParams p)
     }
 }
 
-// Does the block grid of one camera hold any foreground inside pixel box `bb`?  Conservative
-// (block granularity); boxes taller than 8 or wider than 64 blocks count as "maybe".
-__device__ __forceinline__ bool box_may_hit(const uint32_t *__restrict__ g, uint64_t bb,
-                                            uint32_t gshift, uint32_t gws)
+// A word's pixel box against one camera's block grids.  0: no foreground block in the box -- none of
+// its voxels can pass; 2: every voxel lands inside the image (kBoxAllInside) and every block the box
+// touches is entirely foreground -- all of its voxels pass, no table or mask read needed; 1: undecided.
+// Conservative (block granularity); boxes taller than 8 or wider than 64 blocks are undecided.
+constexpr uint64_t kBoxAllInside = 1ull << 63;    // flag in the box word (mask heights < 32768)
+
+__device__ __forceinline__ uint32_t box_test(const uint32_t *__restrict__ g_any, const uint32_t *__restrict__ g_all,
+                                             uint64_t bb, uint32_t gshift, uint32_t gws)
 {
-    if (bb == kEmptyBox) return false;
+    if (bb == kEmptyBox) return 0;
     const uint32_t bu0 = (uint32_t)(bb & 0xffffu) >> gshift, bv0 = (uint32_t)((bb >> 16) & 0xffffu) >> gshift;
-    const uint32_t bu1 = (uint32_t)((bb >> 32) & 0xffffu) >> gshift, bv1 = (uint32_t)(bb >> 48) >> gshift;
-    if (bv1 - bv0 > 7u || bu1 - bu0 > 63u) return true;
+    const uint32_t bu1 = (uint32_t)((bb >> 32) & 0xffffu) >> gshift, bv1 = (uint32_t)((bb >> 48) & 0x7fffu) >> gshift;
+    if (bv1 - bv0 > 7u || bu1 - bu0 > 63u) return 1;
     const uint32_t w0 = bu0 >> 5, w1 = bu1 >> 5;
-    uint32_t any = 0;
+    uint32_t any = 0, miss = 0;
     for (uint32_t r = bv0; r <= bv1; ++r) {
-        const uint32_t *row = g + (size_t)r * gws;
         for (uint32_t w = w0; w <= w1; ++w) {
             uint32_t m = 0xffffffffu;
             if (w == w0) m &= 0xffffffffu << (bu0 & 31u);
             if (w == w1) m &= 0xffffffffu >> (31u - (bu1 & 31u));
-            any |= row[w] & m;
+            any |= g_any[(size_t)r * gws + w] & m;
+            miss |= ~g_all[(size_t)r * gws + w] & m;
         }
     }
-    return any != 0;
+    if (any == 0) return 0;
+    return (miss == 0 && (bb & kBoxAllInside)) ? 2u : 1u;
 }
 
 // HIER = false: refines the alive words k_lut_first left, cameras order[1..].
-// HIER = true : no first pass at all -- a word becomes a candidate only if, for EVERY camera,
-//               the block grid (LDS) has foreground inside the word's pixel box; candidates
-//               then take the exact per-voxel test through all cameras.  Exact: a box with no
-//               foreground block cannot contain a foreground pixel of any of its voxels.
-template <int B, bool HIER, int WL, bool PAIR>
+// HIER = true : no first pass at all.  Coarse pass, lane = word: each camera's pixel box of the word
+//               against that camera's block grids (LDS).  Any camera with no foreground block in the
+//               box kills the word; a camera whose box is all-foreground needs no further look; the
+//               others are recorded in the word's `need` mask.  Words with an empty `need` mask are
+//               final (all 64 voxels survive); the rest take the exact per-voxel test, only for the
+//               cameras in their mask.  Exact: the box contains the pixel of every voxel of the word.
+template <int B, bool HIER, bool PAIR>
 __device__ __forceinline__ void lut_refine_body(const CarveParams &p, uint32_t vblock, uint32_t nblocks, uint32_t *s_grid)
 {
-    if (HIER) {
-        const uint32_t total = p.C * p.gh * p.gws;
-        for (uint32_t i = threadIdx.x; i < total; i += kBlock) s_grid[i] = p.blockgrid[i];
+    const uint32_t gridwords = p.C * p.gh * p.gws;
+    if (HIER) {                                                   // both grids into LDS, 16 bytes per lane (buffer padded to 16 B)
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.blockgrid);
+        uint4 *dst = reinterpret_cast<uint4 *>(s_grid);
+        for (uint32_t i = threadIdx.x; i < (2 * gridwords + 3) / 4; i += kBlock) dst[i] = src[i];
         __syncthreads();
     }
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane((vblock * kBlock + threadIdx.x) >> 6);
     const uint32_t nwaves = nblocks * (kBlock / 64);
-    constexpr uint32_t GW = 64 * WL;                              // words per group (WL per lane)
-    const uint32_t ngroups = (uint32_t)(p.n_pad / (64 * GW));
+    const uint32_t ngroups = (uint32_t)(p.n_pad / 4096);         // 64 words of 64 voxels
     const uint64_t nwords = p.n_pad >> 6;
     const uint32_t qfirst = HIER ? 0u : 1u;
-    uint64_t next[WL];
-    if (!HIER) {
-#pragma unroll
-        for (int w = 0; w < WL; ++w) next[w] = (wave0 < ngroups) ? p.words[(uint64_t)wave0 * GW + 64 * w + lane] : 0ull;
-    }
+    uint64_t next = 0;
+    if (!HIER) next = (wave0 < ngroups) ? p.words[(uint64_t)wave0 * 64 + lane] : 0ull;
     for (uint32_t g = wave0; g < ngroups; g += nwaves) {
-        const uint64_t gw = (uint64_t)g * GW;                     // first word of the group
-        uint64_t mine[WL];
+        const uint64_t gw = (uint64_t)g * 64;                     // first word of the group
+        uint64_t mine;
+        uint32_t need = 0xffffffffu;                              // cameras (positions in order[]) still to test exactly
         if (HIER) {
-            // coarse pass: WL words per lane, four cameras' boxes in flight at a time
-            bool cand[WL];
+            // coarse pass, four cameras' boxes in flight at a time
+            bool cand = true;
+            need = 0;
+            for (uint32_t q0 = 0; q0 < p.C && __ballot(cand) != 0; q0 += 4) {
+                uint64_t bb[4];
 #pragma unroll
-            for (int w = 0; w < WL; ++w) cand[w] = true;
-            for (uint32_t q0 = 0; q0 < p.C; q0 += 4) {
-                bool any = false;
+                for (int k = 0; k < 4; ++k)
+                    bb[k] = (q0 + k < p.C) ? p.bbox[(size_t)p.order[q0 + k] * nwords + gw + lane] : 0ull;
 #pragma unroll
-                for (int w = 0; w < WL; ++w) any = any || cand[w];
-                if (__ballot(any) == 0) break;
-                uint64_t bb[WL][4];
-#pragma unroll
-                for (int w = 0; w < WL; ++w)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        bb[w][k] = (q0 + k < p.C) ? p.bbox[(size_t)p.order[q0 + k] * nwords + gw + 64 * w + lane] : 0ull;
-#pragma unroll
-                for (int w = 0; w < WL; ++w)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (q0 + k < p.C && cand[w])
-                            cand[w] = box_may_hit(s_grid + (size_t)p.order[q0 + k] * p.gh * p.gws, bb[w][k], p.gshift, p.gws);
-            }
-            // a candidate word starts with every voxel of the slab alive (padding excluded)
-#pragma unroll
-            for (int w = 0; w < WL; ++w) {
-                const uint64_t j0 = (gw + 64 * w + lane) << 6;
-                mine[w] = 0;
-                if (cand[w] && j0 < p.n) mine[w] = (p.n - j0 >= 64) ? ~0ull : ((1ull << (p.n - j0)) - 1ull);
-            }
-        } else {
-            const uint32_t gn = (g + nwaves < ngroups) ? g + nwaves : g;   // clamped prefetch
-#pragma unroll
-            for (int w = 0; w < WL; ++w) {
-                mine[w] = next[w];
-                next[w] = p.words[(uint64_t)gn * GW + 64 * w + lane];
-            }
-        }
-        uint64_t nz[WL];
-        bool more = false;
-#pragma unroll
-        for (int w = 0; w < WL; ++w) { nz[w] = __ballot(mine[w] != 0); more = more || nz[w] != 0; }
-        while (p.C > qfirst && more) {                            // wave-uniform
-            uint32_t li[B];                                       // 64*w + lane of the word, or ~0u
-            uint32_t alive = 0;
-#pragma unroll
-            for (int b = 0; b < B; ++b) {
-                li[b] = ~0u;
-#pragma unroll
-                for (int w = 0; w < WL; ++w) {
-                    if (li[b] == ~0u && nz[w] != 0) {
-                        const uint32_t l = (uint32_t)__builtin_ctzll(nz[w]);
-                        nz[w] &= nz[w] - 1;
-                        li[b] = 64u * w + l;
-                        const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine[w], (int)l);
-                        const uint32_t whi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine[w] >> 32), (int)l);
-                        const uint64_t wv = ((uint64_t)whi << 32) | wlo;
-                        if ((wv >> lane) & 1ull) alive |= 1u << b;
+                for (int k = 0; k < 4; ++k) {
+                    if (q0 + k < p.C && cand) {
+                        const uint32_t *ga = s_grid + (size_t)p.order[q0 + k] * p.gh * p.gws;
+                        const uint32_t r = box_test(ga, ga + gridwords, bb[k], p.gshift, p.gws);
+                        cand = r != 0;
+                        if (r == 1) need |= 1u << (q0 + k);
                     }
                 }
             }
+            // a live word starts with every voxel of the slab alive (padding excluded)
+            const uint64_t j0 = (gw + lane) << 6;
+            mine = 0;
+            if (cand && j0 < p.n) mine = (p.n - j0 >= 64) ? ~0ull : ((1ull << (p.n - j0)) - 1ull);
+            if (!cand) need = 0;
+        } else {
+            mine = next;
+            const uint32_t gn = (g + nwaves < ngroups) ? g + nwaves : g;   // clamped prefetch
+            next = p.words[(uint64_t)gn * 64 + lane];
+        }
+        uint64_t nz = __ballot(mine != 0 && need != 0);           // words that need the exact pass
+        while (p.C > qfirst && nz != 0) {                         // wave-uniform
+            uint32_t li[B], nd[B];
+            uint32_t alive = 0;
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                li[b] = 64; nd[b] = 0;
+                if (nz != 0) {
+                    li[b] = (uint32_t)__builtin_ctzll(nz);
+                    nz &= nz - 1;
+                    const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, (int)li[b]);
+                    const uint32_t whi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), (int)li[b]);
+                    nd[b] = (uint32_t)__builtin_amdgcn_readlane((int)need, (int)li[b]);
+                    const uint64_t wv = ((uint64_t)whi << 32) | wlo;
+                    if ((wv >> lane) & 1ull) alive |= 1u << b;
+                }
+            }
+            uint32_t ndany = 0;                                   // cameras any word of the batch still needs
+#pragma unroll
+            for (int b = 0; b < B; ++b) ndany |= nd[b];
             for (uint32_t q = qfirst; q < p.C; q += PAIR ? 2 : 1) {
                 // PAIR: two cameras' entries per dependent round trip (their loads and gathers overlap)
+                if (((ndany >> q) & (PAIR ? 3u : 1u)) == 0) continue;   // decided by the boxes for the whole batch
                 const bool two = PAIR && q + 1 < p.C;
                 const uint32_t c = p.order[q], c2 = p.order[two ? q + 1 : q];
                 const int32_t *__restrict__ L = p.lut + (size_t)c * p.n_pad + gw * 64 + lane;
@@ -388,14 +383,16 @@ __device__ __forceinline__ void lut_refine_body(const CarveParams &p, uint32_t v
                 int32_t off[B], off2[B];
                 uint32_t mw[B], mw2[B];
 #pragma unroll
-                for (int b = 0; b < B; ++b) {
-                    off[b] = ((alive >> b) & 1u) ? L[(size_t)li[b] * 64] : -1;
-                    off2[b] = (two && ((alive >> b) & 1u)) ? L2[(size_t)li[b] * 64] : (two ? -1 : 0);
+                for (int b = 0; b < B; ++b) {                     // a camera outside the word's mask counts as passed
+                    const bool t1 = ((nd[b] >> q) & 1u) && ((alive >> b) & 1u);
+                    const bool t2 = two && ((nd[b] >> (q + 1)) & 1u) && ((alive >> b) & 1u);
+                    off[b] = t1 ? L[(size_t)li[b] * 64] : -2;
+                    off2[b] = t2 ? L2[(size_t)li[b] * 64] : -2;
                 }
 #pragma unroll
                 for (int b = 0; b < B; ++b) {
-                    mw[b] = (off[b] >= 0) ? mb[(uint32_t)off[b] >> 5] : 0u;
-                    mw2[b] = (two && off2[b] >= 0) ? mb2[(uint32_t)off2[b] >> 5] : (two ? 0u : ~0u);
+                    mw[b] = (off[b] >= 0) ? mb[(uint32_t)off[b] >> 5] : (off[b] == -2 ? ~0u : 0u);
+                    mw2[b] = (off2[b] >= 0) ? mb2[(uint32_t)off2[b] >> 5] : (off2[b] == -2 ? ~0u : 0u);
                 }
 #pragma unroll
                 for (int b = 0; b < B; ++b)
@@ -404,33 +401,25 @@ __device__ __forceinline__ void lut_refine_body(const CarveParams &p, uint32_t v
             }
 #pragma unroll
             for (int b = 0; b < B; ++b) {
-                if (li[b] != ~0u) {
+                if (li[b] < 64) {
                     const uint64_t nb = __ballot((alive >> b) & 1u);
-#pragma unroll
-                    for (int w = 0; w < WL; ++w)
-                        if (li[b] == 64u * w + lane) mine[w] = nb;
+                    if (lane == li[b]) mine = nb;
                 }
             }
-            more = false;
-#pragma unroll
-            for (int w = 0; w < WL; ++w) more = more || nz[w] != 0;
         }
+        p.words[gw + lane] = mine;
+        uint32_t cnt = (uint32_t)__popcll(mine);
 #pragma unroll
-        for (int w = 0; w < WL; ++w) {
-            p.words[gw + 64 * w + lane] = mine[w];
-            uint32_t cnt = (uint32_t)__popcll(mine[w]);
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
-            if (lane == 0) p.groupcnt[(uint64_t)g * WL + w] = cnt;
-        }
+        for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
+        if (lane == 0) p.groupcnt[g] = cnt;
     }
 }
 
-template <int B, bool HIER, int WL, bool PAIR>
+template <int B, bool HIER, bool PAIR>
 __global__ __launch_bounds__(kBlock) void k_lut_refine(const CarveParams p)
 {
-    extern __shared__ uint32_t s_grid[];                          // HIER: [C][gh][gws]
-    lut_refine_body<B, HIER, WL, PAIR>(p, blockIdx.x, gridDim.x, s_grid);
+    extern __shared__ uint32_t s_grid[];                          // HIER: [2][C][gh][gws]
+    lut_refine_body<B, HIER, PAIR>(p, blockIdx.x, gridDim.x, s_grid);
 }
 
 // ---------------------------------------------------------------- fused carve
@@ -561,15 +550,19 @@ __device__ __forceinline__ uint64_t segment_box(const CamDev &c, double X, doubl
     if (u.hi < 0.0 || v.hi < 0.0 || u.lo >= (double)W || v.lo >= (double)H) return kEmptyBox;
     const uint32_t u0 = u.lo > 0.0 ? (uint32_t)u.lo : 0u, v0 = v.lo > 0.0 ? (uint32_t)v.lo : 0u;
     const uint32_t u1 = u.hi < (double)(W - 1) ? (uint32_t)u.hi : W - 1, v1 = v.hi < (double)(H - 1) ? (uint32_t)v.hi : H - 1;
-    return (uint64_t)u0 | ((uint64_t)v0 << 16) | ((uint64_t)u1 << 32) | ((uint64_t)v1 << 48);
+    // the (conservative) box inside the image => every voxel of the segment is inside the image
+    const bool inside = u.lo >= 0.0 && v.lo >= 0.0 && u.hi < (double)W && v.hi < (double)H;
+    return (uint64_t)u0 | ((uint64_t)v0 << 16) | ((uint64_t)u1 << 32) | ((uint64_t)v1 << 48) | (inside ? kBoxAllInside : 0ull);
 }
 
 __global__ __launch_bounds__(kBlock) void k_carve_fused_hier(const CarveParams p)
 {
-    extern __shared__ uint32_t s_grid[];                          // [C][gh][gws]
+    extern __shared__ uint32_t s_grid[];                          // [2][C][gh][gws]
+    const uint32_t gridwords = p.C * p.gh * p.gws;
     {
-        const uint32_t total = p.C * p.gh * p.gws;
-        for (uint32_t i = threadIdx.x; i < total; i += kBlock) s_grid[i] = p.blockgrid[i];
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.blockgrid);
+        uint4 *dst = reinterpret_cast<uint4 *>(s_grid);
+        for (uint32_t i = threadIdx.x; i < (2 * gridwords + 3) / 4; i += kBlock) dst[i] = src[i];
         __syncthreads();
     }
     const uint32_t lane = threadIdx.x & 63u;
@@ -585,25 +578,35 @@ __global__ __launch_bounds__(kBlock) void k_carve_fused_hier(const CarveParams p
         if (cand) decompose((uint32_t)j0, p.nx, p.ny, ix, iy, izl);
         const double X = p.xs[ix], Z = p.zs[p.z0 + izl];
         const double ya = p.ys[iy], yb = p.ys[iy + 63 < p.ny ? iy + 63 : p.ny - 1];
+        uint32_t need = 0;                                       // cameras still to test voxel by voxel
         for (uint32_t q = 0; q < p.C && __ballot(cand) != 0; ++q) {
             const uint32_t c = p.order[q];
             if (cand) {
                 const uint64_t bb = segment_box(p.cam[c], X, ya, yb, Z, p.H, p.W);
-                if (bb != kMaybeBox) cand = box_may_hit(s_grid + (size_t)c * p.gh * p.gws, bb, p.gshift, p.gws);
+                uint32_t r = 1;
+                if (bb != kMaybeBox) {
+                    const uint32_t *ga = s_grid + (size_t)c * p.gh * p.gws;
+                    r = box_test(ga, ga + gridwords, bb, p.gshift, p.gws);
+                }
+                cand = r != 0;
+                if (r == 1) need |= 1u << q;
             }
         }
-        // ---- fine: lanes = the 64 voxels of one candidate word, exact float64 test
-        uint64_t nz = __ballot(cand);
-        uint64_t mine = 0;
+        // ---- fine: lanes = the 64 voxels of one candidate word, exact float64 test for the cameras in
+        // its mask; a candidate with an empty mask is final (every voxel passes every camera)
+        uint64_t mine = (cand && need == 0) ? ~0ull : 0ull;
+        uint64_t nz = __ballot(cand && need != 0);
         while (nz != 0) {                                         // wave-uniform
             const uint32_t l = (uint32_t)__builtin_ctzll(nz);
             nz &= nz - 1;
+            const uint32_t nd = (uint32_t)__builtin_amdgcn_readlane((int)need, (int)l);
             const uint32_t wix = (uint32_t)__builtin_amdgcn_readlane((int)ix, (int)l);
             const uint32_t wiy = (uint32_t)__builtin_amdgcn_readlane((int)iy, (int)l);
             const uint32_t wiz = (uint32_t)__builtin_amdgcn_readlane((int)izl, (int)l);
             const double VX = p.xs[wix], VY = p.ys[wiy + lane], VZ = p.zs[p.z0 + wiz];
             bool alive = true;
             for (uint32_t q = 0; q < p.C; ++q) {
+                if (!((nd >> q) & 1u)) continue;                  // decided for the whole word by its box
                 const uint32_t c = p.order[q];
                 if (alive) {
                     double u, v;
@@ -665,15 +668,19 @@ __global__ __launch_bounds__(kBlock) void k_build_lut(const CarveParams p, int32
         const uint32_t pu = off >= 0 ? (uint32_t)off - pv * p.W : 0u;
         const uint32_t u0 = wave_min_u32(off >= 0 ? pu : 0xffffu), u1 = wave_max_u32(pu);
         const uint32_t v0 = wave_min_u32(off >= 0 ? pv : 0xffffu), v1 = wave_max_u32(pv);
+        const bool inside = __ballot(off >= 0) == ~0ull;          // every voxel of the word lands in the image
         if ((threadIdx.x & 63u) == 0)
             bbox[(size_t)c * nwords + (j >> 6)] =
-                (u0 == 0xffffu) ? kEmptyBox : ((uint64_t)u0 | ((uint64_t)v0 << 16) | ((uint64_t)u1 << 32) | ((uint64_t)v1 << 48));
+                (u0 == 0xffffu) ? kEmptyBox
+                                : ((uint64_t)u0 | ((uint64_t)v0 << 16) | ((uint64_t)u1 << 32) | ((uint64_t)v1 << 48) |
+                                   (inside ? kBoxAllInside : 0ull));
     }
 }
 
-// "Any foreground pixel in this block" bits of one frame set (blocks of 2^gshift pixels).
+// Two bits per block of 2^gshift x 2^gshift pixels of one frame set: "some pixel is foreground" and
+// "every pixel (inside the image) is foreground".  grid = [any: C][gh][gws] then [all: C][gh][gws].
 __global__ __launch_bounds__(kBlock) void k_blockgrid(const uint32_t *__restrict__ maskbits, uint32_t *__restrict__ grid,
-                                                      uint32_t H, uint32_t W, uint32_t mwords,
+                                                      uint32_t C, uint32_t H, uint32_t W, uint32_t mwords,
                                                       uint32_t gshift, uint32_t gws, uint32_t gh)
 {
     const uint32_t c = blockIdx.y;
@@ -682,13 +689,17 @@ __global__ __launch_bounds__(kBlock) void k_blockgrid(const uint32_t *__restrict
     if (b >= gw * gh) return;
     const uint32_t bv = b / gw, bu = b - bv * gw;
     const uint32_t *mb = maskbits + (size_t)c * mwords;
-    bool any = false;
-    for (uint32_t y = bv << gshift; y < ((bv + 1) << gshift) && y < H && !any; ++y)
+    bool any = false, all = true;
+    for (uint32_t y = bv << gshift; y < ((bv + 1) << gshift) && y < H; ++y)
         for (uint32_t x = bu << gshift; x < ((bu + 1) << gshift) && x < W; ++x) {
             const uint32_t o = y * W + x;
-            if ((mb[o >> 5] >> (o & 31u)) & 1u) { any = true; break; }
+            const bool fg = (mb[o >> 5] >> (o & 31u)) & 1u;
+            any = any || fg;
+            all = all && fg;
         }
-    if (any) atomicOr(&grid[((size_t)c * gh + bv) * gws + (bu >> 5)], 1u << (bu & 31u));
+    const size_t w = ((size_t)c * gh + bv) * gws + (bu >> 5);
+    if (any) atomicOr(&grid[w], 1u << (bu & 31u));
+    if (all) atomicOr(&grid[(size_t)C * gh * gws + w], 1u << (bu & 31u));
 }
 
 __global__ __launch_bounds__(kBlock) void k_project(const CamDev cam, const double *__restrict__ xyz,

@@ -169,7 +169,6 @@ struct vc_ctx {
     int refine_blocks_per_cu = 8;    // k_lut_refine workgroups (256 threads) per CU
     int fused_blocks_per_cu = 8;     // k_carve_fused workgroups (256 threads) per CU
     int reorder = 1;                 // visit the most selective camera first
-    int refine_wl = 1;               // words per lane in the hierarchical kernel's groups: 1 or 2
     int hier_blocks_per_cu = 48;     // hierarchical kernel: oversubscribed grid, the dispatcher balances uneven groups
     int refine_pair = 1;             // hierarchical LUT kernel: two cameras per dependent round trip
     int emit_lanes = 1;              // record expansion: lanes = voxels of a word (1) or lanes = survivors (0)
@@ -447,7 +446,7 @@ int vc_set_cameras(vc_ctx *ctx, uint32_t C, const double *K9, const double *dist
     if (!ctx || !K9 || !dist5 || !R9 || !t3) return VC_ERR_ARG;
     if (ctx->npending) return fail(ctx, VC_ERR_ARG, "carve steps are in flight: collect them with vc_carve_end first");
     if (C == 0 || C > VC_MAX_CAMERAS) return fail(ctx, VC_ERR_ARG, "camera count %u not in [1,%d]", C, VC_MAX_CAMERAS);
-    if (H == 0 || W == 0 || (uint64_t)H * W > 0x7fffffffull) return fail(ctx, VC_ERR_ARG, "bad mask size %ux%u", H, W);
+    if (H == 0 || W == 0 || H > 32767 || W > 65535) return fail(ctx, VC_ERR_ARG, "mask size %ux%u outside 1..32767 x 1..65535", H, W);
     for (uint32_t c = 0; c < C; ++c) {
         CamDev &d = ctx->cams[c];
         memcpy(d.r, R9 + 9 * c, sizeof d.r);
@@ -461,12 +460,12 @@ int vc_set_cameras(vc_ctx *ctx, uint32_t C, const double *K9, const double *dist
     const bool reshaped = (C != ctx->C || H != ctx->H || W != ctx->W);
     ctx->C = C; ctx->H = H; ctx->W = W;
     ctx->mwords = (uint32_t)(((uint64_t)H * W + 31) / 32);
-    // foreground-block grid: finest power-of-two block whose C grids fit 48 KB of LDS
+    // foreground-block grids (any / all): finest power-of-two block whose 2 C grids fit 48 KB of LDS
     for (ctx->gshift = 2; ctx->gshift < 12; ++ctx->gshift) {
         const uint32_t gw = (W + (1u << ctx->gshift) - 1) >> ctx->gshift;
         ctx->gh = (H + (1u << ctx->gshift) - 1) >> ctx->gshift;
         ctx->gws = (gw + 31) / 32;
-        if ((size_t)C * ctx->gh * ctx->gws * sizeof(uint32_t) <= 48 * 1024) break;
+        if (2 * (size_t)C * ctx->gh * ctx->gws * sizeof(uint32_t) <= 48 * 1024) break;
     }
     ctx->have_cams = true;
     if (reshaped) {
@@ -509,12 +508,12 @@ int vc_upload_masks(vc_ctx *ctx, uint32_t slot, const uint8_t *masks)
                        ctx->C, (uint32_t)HW, ctx->mwords);
     VC_HIP(ctx, hipGetLastError());
     {
-        const size_t gwords = (size_t)ctx->C * ctx->gh * ctx->gws;
-        VC_TRY(ensure(ctx, s->grid, gwords));
+        const size_t gwords = 2 * (size_t)ctx->C * ctx->gh * ctx->gws;
+        VC_TRY(ensure(ctx, s->grid, gwords + 4));                 // + padding: kernels copy it 16 bytes at a time
         VC_HIP(ctx, hipMemsetAsync(s->grid.ptr, 0, gwords * sizeof(uint32_t), ctx->stream));
         const uint32_t gw = (ctx->W + (1u << ctx->gshift) - 1) >> ctx->gshift;
         dim3 gg((gw * ctx->gh + kBlock - 1) / kBlock, ctx->C);
-        hipLaunchKernelGGL(k_blockgrid, gg, dim3(kBlock), 0, ctx->stream, s->bits.ptr, s->grid.ptr, ctx->H, ctx->W,
+        hipLaunchKernelGGL(k_blockgrid, gg, dim3(kBlock), 0, ctx->stream, s->bits.ptr, s->grid.ptr, ctx->C, ctx->H, ctx->W,
                            ctx->mwords, ctx->gshift, ctx->gws, ctx->gh);
         VC_HIP(ctx, hipGetLastError());
     }
@@ -698,17 +697,14 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
         const dim3 grid((uint32_t)(want < gmax ? want : gmax));
         if (mode == VC_MODE_LUT && ctx->lut_hier) {
             // one launch: word-level rejection by pixel box x foreground-block grid, exact test for the rest
-            const size_t lds = (size_t)ctx->C * ctx->gh * ctx->gws * sizeof(uint32_t);
-            const int wl = ctx->refine_wl;
-            const uint64_t groups = p.n_pad / (4096 * wl);
+            const size_t lds = (2 * (size_t)ctx->C * ctx->gh * ctx->gws + 4) * sizeof(uint32_t);
+            const uint64_t groups = p.n_pad / 4096;
             const uint64_t rwant = (groups + 3) / 4;
             const uint64_t rmax = 256ull * (uint64_t)ctx->hier_blocks_per_cu;
             const dim3 rgrid((uint32_t)(rwant < rmax ? rwant : rmax));
-            if (ctx->refine_pair) hipLaunchKernelGGL((k_lut_refine<8, true, 1, true>), rgrid, block, lds, ctx->stream, p);
-            else if (ctx->refine_b == 8 && wl == 1) hipLaunchKernelGGL((k_lut_refine<8, true, 1, false>), rgrid, block, lds, ctx->stream, p);
-            else if (ctx->refine_b == 8) hipLaunchKernelGGL((k_lut_refine<8, true, 2, false>), rgrid, block, lds, ctx->stream, p);
-            else if (wl == 1) hipLaunchKernelGGL((k_lut_refine<16, true, 1, false>), rgrid, block, lds, ctx->stream, p);
-            else hipLaunchKernelGGL((k_lut_refine<16, true, 2, false>), rgrid, block, lds, ctx->stream, p);
+            if (ctx->refine_pair) hipLaunchKernelGGL((k_lut_refine<8, true, true>), rgrid, block, lds, ctx->stream, p);
+            else if (ctx->refine_b == 8) hipLaunchKernelGGL((k_lut_refine<8, true, false>), rgrid, block, lds, ctx->stream, p);
+            else hipLaunchKernelGGL((k_lut_refine<16, true, false>), rgrid, block, lds, ctx->stream, p);
             VC_HIP(ctx, hipEventRecord(sb.e_first, ctx->stream));
             sb.has_first = true;
         } else if (mode == VC_MODE_LUT) {
@@ -731,14 +727,14 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
             const uint64_t rwant = (groups + 3) / 4;
             const uint64_t rmax = 256ull * (uint64_t)ctx->refine_blocks_per_cu;
             const dim3 rgrid((uint32_t)(rwant < rmax ? rwant : rmax));
-            if (ctx->refine_b == 8) hipLaunchKernelGGL((k_lut_refine<8, false, 1, false>), rgrid, block, 0, ctx->stream, p);
-            else hipLaunchKernelGGL((k_lut_refine<16, false, 1, false>), rgrid, block, 0, ctx->stream, p);
+            if (ctx->refine_b == 8) hipLaunchKernelGGL((k_lut_refine<8, false, false>), rgrid, block, 0, ctx->stream, p);
+            else hipLaunchKernelGGL((k_lut_refine<16, false, false>), rgrid, block, 0, ctx->stream, p);
         }
         else if (ctx->ny % 64 == 0 && ctx->fused_hier) {
-            const size_t lds = (size_t)ctx->C * ctx->gh * ctx->gws * sizeof(uint32_t);
+            const size_t lds = (2 * (size_t)ctx->C * ctx->gh * ctx->gws + 4) * sizeof(uint32_t);
             const uint64_t groups = p.n_pad / 4096;
             const uint64_t rwant = (groups + 3) / 4;
-            const uint64_t rmax = 256ull * 2 * (uint64_t)ctx->hier_blocks_per_cu;      // more, shorter workgroups: 96/CU measured best
+            const uint64_t rmax = 256ull * (uint64_t)ctx->hier_blocks_per_cu;
             const dim3 rgrid((uint32_t)(rwant < rmax ? rwant : rmax));
             hipLaunchKernelGGL(k_carve_fused_hier, rgrid, block, lds, ctx->stream, p);
         }
@@ -931,7 +927,6 @@ int vc_set_option(vc_ctx *ctx, const char *name, int value)
     else if (k == "fused_hier") ctx->fused_hier = value != 0;
     else if (k == "emit_lanes") ctx->emit_lanes = value != 0;
     else if (k == "refine_pair") ctx->refine_pair = value != 0;
-    else if (k == "refine_wl" && (value == 1 || value == 2)) ctx->refine_wl = value;
     else if (k == "hier_blocks_per_cu" && value >= 1 && value <= 4096) ctx->hier_blocks_per_cu = value;
     else if (k == "first_kv" && (value == 1 || value == 2 || value == 4)) ctx->first_kv = value;
     else if (k == "first_blocks_per_cu" && value >= 1 && value <= 8) ctx->first_blocks_per_cu = value;
