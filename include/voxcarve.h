@@ -43,7 +43,9 @@ typedef enum {
 } vc_mode;
 
 enum {
-    VC_FLAG_VIEWMASK = 1u  /* also keep the per-voxel camera bitmask (compat dicts) */
+    VC_FLAG_VIEWMASK = 1u,   /* also keep the per-voxel camera bitmask (compat dicts) */
+    VC_FLAG_NO_RECORDS = 2u  /* count + occupancy only: the records are produced by vc_allgather /
+                                vc_expand_entries (a rank of a multi-GPU job never reads its own slab's list) */
 };
 
 #define VC_MAX_CAMERAS 16
@@ -61,6 +63,7 @@ typedef struct {
     float carve_ms_sum; /* summed carve kernel time since vc_timing_reset              */
     float first_ms;     /* VC_MODE_LUT: the first-camera streaming kernel of the last carve */
     float first_ms_sum; /* summed since vc_timing_reset                                 */
+    float exchange_ms;  /* vc_allgather, compact form: pack + RCCL part of gather_ms         */
 } vc_timing_t;
 
 /* ---- lifetime ------------------------------------------------------------------ */
@@ -145,8 +148,22 @@ int vc_comm_unique_id(uint8_t out[VC_UNIQUE_ID_BYTES]);
 int vc_comm_init(vc_ctx *ctx, int n_ranks, int rank, const uint8_t uid[VC_UNIQUE_ID_BYTES]);
 int vc_comm_destroy(vc_ctx *ctx);
 /* All-gather of every rank's survivor records in rank (= z-slab = index) order.
- * counts_out (NULL ok): n_ranks entries.  *total_out = global survivor count. */
+ * counts_out (NULL ok): n_ranks entries.  *total_out = global survivor count.
+ * What crosses xGMI is the compact form below (option "gather_compact", default 1): each rank's
+ * non-zero occupancy words; every rank expands all of them into the full record list itself, taking
+ * colours from its own copy of the colour camera's table over the whole grid (VC_MODE_LUT: 4 B per
+ * voxel of the whole grid, built at the first call) or by re-projection (VC_MODE_FUSED).  With the
+ * option off the 8-byte records themselves are exchanged. */
 int vc_allgather(vc_ctx *ctx, uint64_t *counts_out, uint64_t *total_out);
+/* The compact form for host-side transports (and tests): entries = pairs of u64 {occupancy bits of one
+ * 64-voxel word, global linear index of its bit 0}, non-zero words only, ascending.
+ * vc_pack_entries packs the last carve's slab; vc_fetch_entries copies 2*n u64 out;
+ * vc_expand_entries takes the concatenation of all ranks' entries in rank order and leaves the ordered
+ * records of the whole grid where vc_fetch_gathered reads them, coloured like the last carve of THIS
+ * context (same mode, colour camera and frame set). */
+int vc_pack_entries(vc_ctx *ctx, uint64_t *n_entries_out);
+int vc_fetch_entries(vc_ctx *ctx, uint64_t *entries);
+int vc_expand_entries(vc_ctx *ctx, const uint64_t *entries, uint64_t n_entries, uint64_t *total_out);
 int vc_fetch_gathered(vc_ctx *ctx, uint64_t *records);
 /* Max of one double over all ranks via RCCL (doubles as a barrier for host code). */
 int vc_comm_allreduce_max(vc_ctx *ctx, double *inout);

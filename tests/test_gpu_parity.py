@@ -349,17 +349,84 @@ def test_overlapped_steps_begin_end(eng, cams, masks, frames):
     eng.carve_end()
 
 
+@pytest.mark.parametrize("grid", [(64, 64, 64), (33, 31, 20), (128, 64, 96)])
+def test_compact_exchange_slab_entries_expand_to_the_full_list(eng, cams, masks, frames, grid):
+    """What crosses xGMI in vc_allgather: each slab's non-zero occupancy words as {bits, base} pairs.  G slabs carved
+    one after the other on this GPU, their pairs concatenated in rank order and expanded on the device ==
+    the record list of the whole grid (index, order, colour, seen flag), for both modes, for a threshold below C
+    (colour camera not always seeing the voxel) and for slabs whose voxel count is not a multiple of 64."""
+    from voxcarve import slabs
+    from voxcarve._lib import VoxcarveError
+    setup_real(eng, cams, masks, frames, grid)
+    for mode, min_views in (("lut", None), ("fused", None), ("lut", 2), ("fused", 3)):
+        eng.set_slab(0, grid[2])
+        if mode == "lut":
+            eng.build_lut()
+        eng.carve(mode=mode, min_views=min_views)
+        full = eng.fetch_records()
+        assert full.size > 0
+        ent = eng.pack_entries()
+        assert np.all(ent[:, 0] != 0) and np.all(np.diff(ent[:, 1].astype(np.int64)) > 0)
+        assert int(np.bitwise_count(ent[:, 0]).sum()) == full.size
+        assert eng.expand_entries(ent) == full.size
+        assert np.array_equal(eng.fetch_gathered(), full)
+        for G in (2, 3, 7):
+            parts = []
+            for r in range(G):
+                z0, z1 = slabs.slab_range(grid[2], G, r)
+                eng.set_slab(z0, z1)
+                if mode == "lut":
+                    eng.build_lut()
+                n_r = eng.carve(mode=mode, min_views=min_views, records=False)
+                with pytest.raises(VoxcarveError, match="NO_RECORDS"):
+                    eng.fetch_records()
+                parts.append(eng.pack_entries())
+                assert int(np.bitwise_count(parts[-1][:, 0]).sum()) == n_r
+            allent = np.concatenate(parts)
+            assert eng.expand_entries(allent) == full.size        # on the LAST rank's context: colours of remote words
+            assert np.array_equal(eng.fetch_gathered(), full), (mode, min_views, G)
+    assert eng.expand_entries(np.empty((0, 2), np.uint64)) == 0
+    eng.set_slab(0, grid[2])
+
+
 def test_rccl_allgather_single_rank(eng, cams, masks, frames):
-    """The RCCL path (dlopen, communicator, counts all-gather, grouped broadcast) with one rank."""
+    """The RCCL path (dlopen, communicator, counts all-gather, grouped broadcast) with one rank: the compact form
+    (default), the compact form with the counts exchanged inside vc_carve_begin (records=False, steps
+    overlapped), and the record exchange."""
     import voxcarve
     setup_real(eng, cams, masks, frames, (64, 64, 64))
+    rolled = [np.roll(m, 5, axis=1) for m in masks]
+    eng.upload_masks(rolled, slot=1)
+    eng.upload_frame(1, frames[1], slot=1)
+    eng.build_lut()
     n = eng.carve()
     uid = voxcarve.CarveEngine.comm_unique_id()
     eng.comm_init(1, 0, uid)
     assert np.array_equal(eng.fetch_records(pinned=True), eng.fetch_records())     # page-locked read-back path
-    counts, total = eng.allgather()
-    assert counts.tolist() == [n] and total == n
-    assert np.array_equal(eng.fetch_gathered(), eng.fetch_records())
+    for compact in (1, 0):
+        eng.set_option("gather_compact", compact)
+        counts, total = eng.allgather()
+        assert counts.tolist() == [n] and total == n
+        assert np.array_equal(eng.fetch_gathered(), eng.fetch_records())
+    eng.set_option("gather_compact", 1)
+    for mode in ("lut", "fused"):
+        want = []
+        for slot in (0, 1, 1, 0):
+            eng.carve(slot=slot, mode=mode)
+            want.append(eng.fetch_records())
+        got = []
+        eng.carve_begin(slot=0, mode=mode, records=False)
+        for slot in (1, 1, 0):
+            eng.carve_begin(slot=slot, mode=mode, records=False)
+            n_i = eng.carve_end()
+            counts, total = eng.allgather()
+            assert counts.tolist() == [n_i] and total == n_i
+            got.append(eng.fetch_gathered())
+        eng.carve_end()
+        eng.allgather()
+        got.append(eng.fetch_gathered())
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b), mode
     eng.comm_destroy()
 
 

@@ -13,6 +13,7 @@ VC_OK = 0
 VC_MODE_FUSED = 0
 VC_MODE_LUT = 1
 VC_FLAG_VIEWMASK = 1
+VC_FLAG_NO_RECORDS = 2
 VC_MAX_CAMERAS = 16
 VC_UNIQUE_ID_BYTES = 128
 
@@ -34,7 +35,7 @@ class VcTiming(ctypes.Structure):
                 ("h2d_ms", ctypes.c_float), ("voxels", ctypes.c_uint64),
                 ("survivors", ctypes.c_uint64), ("carve_launches", ctypes.c_uint32),
                 ("carve_ms_sum", ctypes.c_float), ("first_ms", ctypes.c_float),
-                ("first_ms_sum", ctypes.c_float)]
+                ("first_ms_sum", ctypes.c_float), ("exchange_ms", ctypes.c_float)]
 
 
 # name -> (restype, argtypes); every symbol include/voxcarve.h declares.
@@ -74,6 +75,9 @@ SIGNATURES = {
     "vc_comm_destroy": (ctypes.c_int, [c_ctx]),
     "vc_allgather": (ctypes.c_int, [c_ctx, c_u64p, c_u64p]),
     "vc_fetch_gathered": (ctypes.c_int, [c_ctx, c_u64p]),
+    "vc_pack_entries": (ctypes.c_int, [c_ctx, c_u64p]),
+    "vc_fetch_entries": (ctypes.c_int, [c_ctx, c_u64p]),
+    "vc_expand_entries": (ctypes.c_int, [c_ctx, c_u64p, ctypes.c_uint64, c_u64p]),
     "vc_comm_allreduce_max": (ctypes.c_int, [c_ctx, c_f64p]),
 }
 

@@ -44,6 +44,7 @@ struct EmitParams {
     const uint32_t *frame;      // colour camera's image as one BGRX dword per pixel (or null)
     const int32_t *lut;         // colour camera's packed table (FROM_LUT), else null
     const uint64_t *words;
+    const uint64_t *entries;    // INDIRECT expansion: {bits, global index of bit 0} pairs instead of words
     const uint32_t *groupcnt;   // survivors per group
     const uint32_t *groupoff;   // exclusive scan of groupcnt inside each scan block
     const uint64_t *blockoff;   // exclusive scan of the scan blocks' sums
@@ -669,7 +670,7 @@ __global__ __launch_bounds__(kBlock) void k_build_lut(const CarveParams p, int32
         const uint32_t u0 = wave_min_u32(off >= 0 ? pu : 0xffffu), u1 = wave_max_u32(pu);
         const uint32_t v0 = wave_min_u32(off >= 0 ? pv : 0xffffu), v1 = wave_max_u32(pv);
         const bool inside = __ballot(off >= 0) == ~0ull;          // every voxel of the word lands in the image
-        if ((threadIdx.x & 63u) == 0)
+        if (bbox && (threadIdx.x & 63u) == 0)
             bbox[(size_t)c * nwords + (j >> 6)] =
                 (u0 == 0xffffu) ? kEmptyBox
                                 : ((uint64_t)u0 | ((uint64_t)v0 << 16) | ((uint64_t)u1 << 32) | ((uint64_t)v1 << 48) |
@@ -735,6 +736,54 @@ __global__ __launch_bounds__(kBlock) void k_count_groups(const uint64_t *__restr
     if (g >= ngroups) return;
     const uint64_t w = (uint64_t)g * kGroupWords + lane;
     uint32_t cnt = (w < nwords) ? (uint32_t)__popcll(words[w]) : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
+    if (lane == 0) groupcnt[g] = cnt;
+}
+
+// ---- compact exchange form of a carve result (multi-GPU): the non-zero words of the slab as
+// {bits, global index of bit 0} pairs, ascending.  A slab's hull fills ~1 word in 25, so the pairs
+// are ~30x smaller than the survivor records they expand to.
+__global__ __launch_bounds__(kBlock) void k_count_nz(const uint64_t *__restrict__ words, uint64_t nwords,
+                                                     uint32_t ngroups, uint32_t *__restrict__ groupcnt)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t g = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    if (g >= ngroups) return;
+    const uint64_t w = (uint64_t)g * kGroupWords + lane;
+    const uint64_t nz = __ballot(w < nwords && words[w] != 0ull);
+    if (lane == 0) groupcnt[g] = (uint32_t)__popcll(nz);
+}
+
+// mine[0] = entry count, mine[1] = survivor count of this rank (what the counts all-gather sends).
+__global__ __launch_bounds__(kBlock) void k_pack_entries(const uint64_t *__restrict__ words, uint64_t nwords,
+                                                         uint32_t ngroups, const uint32_t *__restrict__ groupoff,
+                                                         const uint64_t *__restrict__ blockoff, uint32_t nscan,
+                                                         uint64_t i0, const uint64_t *__restrict__ survivors,
+                                                         uint64_t *__restrict__ entries, uint64_t *__restrict__ mine)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t g = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { mine[0] = blockoff[nscan]; mine[1] = *survivors; }
+    if (g >= ngroups) return;
+    const uint64_t w = (uint64_t)g * kGroupWords + lane;
+    const uint64_t bits = (w < nwords) ? words[w] : 0ull;
+    const uint64_t nz = __ballot(bits != 0ull);
+    if (bits != 0ull) {
+        const uint64_t o = blockoff[g / kScanBlock] + groupoff[g] + (uint32_t)__popcll(nz & ((1ull << lane) - 1ull));
+        entries[2 * o] = bits;
+        entries[2 * o + 1] = i0 + (w << 6);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_count_entries(const uint64_t *__restrict__ entries, uint64_t nent,
+                                                          uint32_t ngroups, uint32_t *__restrict__ groupcnt)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t g = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    if (g >= ngroups) return;
+    const uint64_t w = (uint64_t)g * kGroupWords + lane;
+    uint32_t cnt = (w < nent) ? (uint32_t)__popcll(entries[2 * w]) : 0u;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
     if (lane == 0) groupcnt[g] = cnt;
@@ -908,7 +957,9 @@ __global__ __launch_bounds__(kBlock) void k_emit_words(const EmitParams p)
 // Variant of the expansion with lanes = the 64 voxels of a word: a survivor's rank inside its
 // word is the count of set bits below its lane (no search at all), at the price of idle lanes in
 // sparse words (the hull's words are dense: ~44 of 64 bits).  EB words are expanded together.
-template <bool FROM_LUT, bool ALLSEEN, int EB>
+// INDIRECT: the "words" are gathered {bits, base} entries of all ranks (p.n = 64 x entries, p.lut =
+// the colour camera's table over the WHOLE grid, p.z0 = p.i0 = 0): voxel index = base + lane.
+template <bool FROM_LUT, bool ALLSEEN, int EB, bool INDIRECT = false>
 __global__ __launch_bounds__(kBlock) void k_emit_lanes(const EmitParams p)
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -918,20 +969,29 @@ __global__ __launch_bounds__(kBlock) void k_emit_lanes(const EmitParams p)
     const uint64_t nwords = (p.n + 63) >> 6;
     const uint64_t out0 = p.blockoff[g / kScanBlock] + p.groupoff[g];
     const uint64_t gw = (uint64_t)g * kGroupWords;
-    const uint64_t mine = (gw + lane < nwords) ? p.words[gw + lane] : 0ull;
+    uint64_t mine = 0ull;
+    uint32_t mybase = 0;
+    if (gw + lane < nwords) {
+        if (INDIRECT) {
+            const ulonglong2 e = reinterpret_cast<const ulonglong2 *>(p.entries)[gw + lane];
+            mine = e.x; mybase = (uint32_t)e.y;
+        } else mine = p.words[gw + lane];
+    }
     const uint32_t c = (uint32_t)__popcll(mine);
     const uint32_t wstart = wave_inclusive_scan(c, lane) - c;           // first record of my word in the group
     const uint64_t below = (1ull << lane) - 1ull;
     uint64_t nz = __ballot(mine != 0);
     while (nz != 0) {                                                   // wave-uniform
-        uint32_t li[EB], ws[EB];
+        uint32_t li[EB], ws[EB], jb[EB];
         uint64_t wv[EB];
 #pragma unroll
         for (int b = 0; b < EB; ++b) {
-            li[b] = 0; wv[b] = 0; ws[b] = 0;
+            li[b] = 0; wv[b] = 0; ws[b] = 0; jb[b] = 0;
             if (nz != 0) {
                 li[b] = (uint32_t)__builtin_ctzll(nz);
                 nz &= nz - 1;
+                jb[b] = INDIRECT ? (uint32_t)__builtin_amdgcn_readlane((int)mybase, (int)li[b])
+                                 : (uint32_t)((gw + li[b]) << 6);
                 const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, (int)li[b]);
                 const uint32_t whi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), (int)li[b]);
                 wv[b] = ((uint64_t)whi << 32) | wlo;
@@ -943,7 +1003,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_lanes(const EmitParams p)
         for (int b = 0; b < EB; ++b) {
             off[b] = -1;
             if (p.has_cam && ((wv[b] >> lane) & 1ull)) {
-                const uint32_t j = (uint32_t)((gw + li[b]) << 6) + lane;
+                const uint32_t j = jb[b] + lane;
                 if (FROM_LUT) {
                     off[b] = p.lut[j];
                 } else {
@@ -958,7 +1018,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_lanes(const EmitParams p)
         uint64_t rec[EB];
 #pragma unroll
         for (int b = 0; b < EB; ++b) {
-            rec[b] = (uint32_t)(p.i0 + ((gw + li[b]) << 6) + lane);
+            rec[b] = (uint32_t)(p.i0 + jb[b] + lane);
             if (off[b] >= 0 && (ALLSEEN || (p.maskbits && mask_bit(p.maskbits, off[b])))) {
                 const uint64_t px = p.frame ? (uint64_t)p.frame[off[b]] : 0ull;           // B | G<<8 | R<<16
                 rec[b] |= ((px >> 16) & 0xffull) << 32 | ((px >> 8) & 0xffull) << 40 | (px & 0xffull) << 48 | (1ull << 56);

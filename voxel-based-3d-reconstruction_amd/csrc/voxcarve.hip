@@ -127,6 +127,13 @@ struct StepBuf {
     bool pending = false, used = false;
     EmitParams emit;                         // kept for a re-run after a records regrow
     bool allseen = false, want_vm = false, has_first = false;
+    bool no_records = false;                 // VC_FLAG_NO_RECORDS: occupancy words + count only
+    // compact exchange form of this step: non-zero words as {bits, global index of bit 0} pairs
+    DevBuf<uint64_t> ent, mine, counts;      // pairs | {entries, survivors} of this rank | of all ranks
+    uint64_t *h_counts = nullptr;            // pinned, 2 per rank
+    bool counts_exchanged = false;           // vc_carve_begin already packed and all-gathered the counts
+    int mode = 0, color_cam = -1;            // what the step was run with (vc_expand_entries colours the same way)
+    uint32_t slot = 0;
     uint64_t n = 0, survivors = 0;
 };
 
@@ -187,6 +194,16 @@ struct vc_ctx {
     uint64_t *h_counts = nullptr;    // pinned, n_ranks
     uint64_t gathered_total = 0;
     bool gathered = false;
+    // compact exchange: non-zero words of the slab as {bits, global index of bit 0} pairs
+    int gather_compact = 1;          // vc_allgather exchanges the pairs and expands them on every rank
+    DevBuf<uint64_t> d_ent_all;              // all ranks' pairs in rank order
+    DevBuf<uint32_t> d_xcnt, d_xoff;         // scan scratch of the pack and expand passes (stream-ordered)
+    DevBuf<uint64_t> d_xbsum, d_xboff;
+    uint64_t *h_xtotal = nullptr;            // pinned
+    uint64_t packed_entries = 0;
+    bool packed = false;
+    DevBuf<int32_t> d_lut_color;             // colour camera's table over the WHOLE grid (expansion of remote words)
+    int lut_color_cam = -1;
 
     vc_timing_t tm;
 
@@ -296,11 +313,144 @@ int launch_emit(vc_ctx *ctx, StepBuf &sb, hipStream_t st)
     return VC_OK;
 }
 
+constexpr int VC_MAX_RANKS = 64;
 constexpr uint32_t kMaxScanBlocks = 1024;  // 2^32 voxels / 4096 per group / 1024 groups per scan block
 constexpr int kSub = 4;                    // 64-voxel sub-chunks per wavefront chunk (fused kernel)
 constexpr size_t kLdsBytes = 160 * 1024;   // LDS per CU on gfx950
 constexpr size_t kMaxFirstLds = 64 * 1024; // static limit of one workgroup's dynamic LDS without opt-in
 constexpr uint32_t kEstimateSamples = 1u << 16;
+
+// counts -> exclusive offsets (two levels) on the context's stream; the total also lands in *total_host
+int scan_counts(vc_ctx *ctx, const uint32_t *cnt, uint32_t ngroups, uint32_t *off, uint64_t *bsum, uint64_t *boff,
+                uint64_t *total_host)
+{
+    const uint32_t nscan = (ngroups + kScanBlock - 1) / kScanBlock;
+    hipLaunchKernelGGL(k_scan_groups, dim3(nscan), dim3(kScanBlock), 0, ctx->stream, cnt, ngroups, off, bsum, boff, total_host);
+    VC_HIP(ctx, hipGetLastError());
+    if (nscan > 1) {
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(kScanBlock), 0, ctx->stream, bsum, nscan, boff, total_host);
+        VC_HIP(ctx, hipGetLastError());
+    }
+    return VC_OK;
+}
+
+int ensure_exchange_scratch(vc_ctx *ctx, uint32_t ngroups)
+{
+    VC_TRY(ensure(ctx, ctx->d_xcnt, ngroups));
+    VC_TRY(ensure(ctx, ctx->d_xoff, ngroups));
+    VC_TRY(ensure(ctx, ctx->d_xbsum, kMaxScanBlocks));
+    VC_TRY(ensure(ctx, ctx->d_xboff, kMaxScanBlocks + 1));
+    if (!ctx->h_xtotal)
+        VC_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_xtotal), 2 * sizeof(uint64_t), hipHostMallocDefault));
+    return VC_OK;
+}
+
+// Enqueues the packing of the current result's non-zero words into ctx->d_ent ({bits, base} pairs) and
+// {entries, survivors} into ctx->d_mine.  No host synchronisation; *h_xtotal holds the entry count
+// once the stream has drained.
+int enqueue_pack(vc_ctx *ctx, StepBuf &cur)
+{
+    const uint64_t n = cur.n;
+    VC_TRY(ensure_exchange_scratch(ctx, 1));
+    VC_TRY(ensure(ctx, cur.mine, 2));
+    if (n == 0) {
+        VC_HIP(ctx, hipMemsetAsync(cur.mine.ptr, 0, 2 * sizeof(uint64_t), ctx->stream));
+        *ctx->h_xtotal = 0;
+        return VC_OK;
+    }
+    const uint64_t nwords = (n + 63) / 64;
+    const uint64_t n_pad = (n + kLutPad - 1) / kLutPad * kLutPad;
+    const uint32_t ngroups = (uint32_t)(n_pad / (64 * kGroupWords));
+    const uint32_t nscan = (ngroups + kScanBlock - 1) / kScanBlock;
+    VC_TRY(ensure_exchange_scratch(ctx, ngroups));
+    VC_TRY(ensure(ctx, cur.ent, (size_t)(2 * nwords)));          // worst case: every word non-zero (n / 4 bytes)
+    const dim3 grid((ngroups + 3) / 4), block(kBlock);
+    hipLaunchKernelGGL(k_count_nz, grid, block, 0, ctx->stream, cur.words.ptr, nwords, ngroups, ctx->d_xcnt.ptr);
+    VC_HIP(ctx, hipGetLastError());
+    VC_TRY(scan_counts(ctx, ctx->d_xcnt.ptr, ngroups, ctx->d_xoff.ptr, ctx->d_xbsum.ptr, ctx->d_xboff.ptr, ctx->h_xtotal));
+    hipLaunchKernelGGL(k_pack_entries, grid, block, 0, ctx->stream, cur.words.ptr, nwords, ngroups, ctx->d_xoff.ptr,
+                       ctx->d_xboff.ptr, nscan, ctx->i0(), cur.blockoff.ptr + nscan, cur.ent.ptr, cur.mine.ptr);
+    VC_HIP(ctx, hipGetLastError());
+    return VC_OK;
+}
+
+// {entries, survivors} of every rank into cur.h_counts (valid once the stream has drained).
+int enqueue_counts_exchange(vc_ctx *ctx, StepBuf &cur)
+{
+    const int G = ctx->n_ranks;
+    VC_TRY(ensure(ctx, cur.counts, (size_t)2 * G));
+    if (!cur.h_counts)
+        VC_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&cur.h_counts), sizeof(uint64_t) * 2 * VC_MAX_RANKS, hipHostMallocDefault));
+    VC_NCCL(ctx, g_rccl.AllGather(cur.mine.ptr, cur.counts.ptr, 2, ncclUint64, ctx->comm, ctx->stream));
+    VC_HIP(ctx, hipMemcpyAsync(cur.h_counts, cur.counts.ptr, sizeof(uint64_t) * 2 * G, hipMemcpyDeviceToHost, ctx->stream));
+    return VC_OK;
+}
+
+// The colour camera's table over the whole grid (4 B per voxel of the WHOLE grid, built once per
+// camera): what lets a rank colour survivors of words another rank carved.
+int ensure_color_table(vc_ctx *ctx, int cam)
+{
+    if (ctx->lut_color_cam == cam && ctx->d_lut_color.ptr) return VC_OK;
+    const uint64_t n = (uint64_t)ctx->nx * ctx->ny * ctx->nz;
+    const uint64_t n_pad = (n + kLutPad - 1) / kLutPad * kLutPad;
+    VC_TRY(ensure(ctx, ctx->d_lut_color, (size_t)n_pad));
+    CarveParams p;
+    fill_params(ctx, p);
+    p.n = n; p.n_pad = n_pad; p.z0 = 0; p.C = 1;
+    p.cam[0] = ctx->cams[cam];
+    hipLaunchKernelGGL(k_build_lut, dim3(grid_for(n_pad)), dim3(kBlock), 0, ctx->stream, p, ctx->d_lut_color.ptr,
+                       (uint64_t *)nullptr);
+    VC_HIP(ctx, hipGetLastError());
+    ctx->lut_color_cam = cam;
+    return VC_OK;
+}
+
+// Expands M gathered entries (device, ascending) into the ordered survivor records of the whole grid
+// in ctx->d_gathered, coloured the way the current step was (its mode, colour camera and frame set).
+// S_hint = expected survivor count (0 = unknown: sized after a host synchronisation).
+int enqueue_expand(vc_ctx *ctx, const uint64_t *d_entries, uint64_t M, uint64_t S_hint)
+{
+    StepBuf &cur = ctx->sb[ctx->cur];
+    *(ctx->h_xtotal + 1) = 0;
+    if (M == 0) return VC_OK;
+    const uint32_t ngroups = (uint32_t)((M + kGroupWords - 1) / kGroupWords);
+    VC_TRY(ensure_exchange_scratch(ctx, ngroups));
+    const dim3 grid((ngroups + 3) / 4), block(kBlock);
+    hipLaunchKernelGGL(k_count_entries, grid, block, 0, ctx->stream, d_entries, M, ngroups, ctx->d_xcnt.ptr);
+    VC_HIP(ctx, hipGetLastError());
+    VC_TRY(scan_counts(ctx, ctx->d_xcnt.ptr, ngroups, ctx->d_xoff.ptr, ctx->d_xbsum.ptr, ctx->d_xboff.ptr, ctx->h_xtotal + 1));
+    if (S_hint == 0) {
+        VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        S_hint = *(ctx->h_xtotal + 1);
+    }
+    VC_TRY(ensure(ctx, ctx->d_gathered, (size_t)S_hint));
+    EmitParams e;                                // axes, camera, mask bits and frame of the step
+    memset(&e, 0, sizeof e);
+    e.xs = ctx->d_axes.ptr; e.ys = e.xs + ctx->nx; e.zs = e.ys + ctx->ny;
+    e.nx = ctx->nx; e.ny = ctx->ny; e.H = ctx->H; e.W = ctx->W;
+    if (cur.color_cam >= 0) {
+        const Slot &s = ctx->slots[cur.slot];
+        e.has_cam = 1;
+        e.cam = ctx->cams[cur.color_cam];
+        e.maskbits = s.bits.ptr + (size_t)cur.color_cam * ctx->mwords;
+        if (s.frames.ptr && s.have_frame[cur.color_cam]) e.frame = s.frames.ptr + (size_t)cur.color_cam * ctx->H * ctx->W;
+    }
+    e.entries = d_entries;
+    e.groupcnt = ctx->d_xcnt.ptr; e.groupoff = ctx->d_xoff.ptr; e.blockoff = ctx->d_xboff.ptr;
+    e.n = M * 64; e.i0 = 0; e.z0 = 0; e.ngroups = ngroups;
+    e.records = ctx->d_gathered.ptr; e.capacity = ctx->d_gathered.cap;
+    const bool from_lut = cur.mode == VC_MODE_LUT && cur.color_cam >= 0;
+    if (from_lut) {
+        VC_TRY(ensure_color_table(ctx, cur.color_cam));
+        e.lut = ctx->d_lut_color.ptr;
+    } else e.lut = nullptr;
+    if (from_lut && cur.allseen) hipLaunchKernelGGL((k_emit_lanes<true, true, 8, true>), grid, block, 0, ctx->stream, e);
+    else if (from_lut) hipLaunchKernelGGL((k_emit_lanes<true, false, 8, true>), grid, block, 0, ctx->stream, e);
+    else if (cur.allseen) hipLaunchKernelGGL((k_emit_lanes<false, true, 4, true>), grid, block, 0, ctx->stream, e);
+    else hipLaunchKernelGGL((k_emit_lanes<false, false, 4, true>), grid, block, 0, ctx->stream, e);
+    VC_HIP(ctx, hipGetLastError());
+    return VC_OK;
+}
 
 }  // namespace
 
@@ -369,6 +519,8 @@ int vc_destroy(vc_ctx *ctx)
     release(ctx->d_axes); release(ctx->d_stage); release(ctx->d_morph); release(ctx->d_lut); release(ctx->d_bbox);
     for (StepBuf &b : ctx->sb) {
         release(b.words); release(b.groupcnt); release(b.groupoff); release(b.blocksum); release(b.blockoff); release(b.records);
+        release(b.ent); release(b.mine); release(b.counts);
+        if (b.h_counts) (void)hipHostFree(b.h_counts);
         if (b.h_total) (void)hipHostFree(b.h_total);
         if (b.e0) (void)hipEventDestroy(b.e0);
         if (b.e_first) (void)hipEventDestroy(b.e_first);
@@ -376,6 +528,9 @@ int vc_destroy(vc_ctx *ctx)
         if (b.e2) (void)hipEventDestroy(b.e2);
     }
     release(ctx->d_viewmask); release(ctx->d_scratch); release(ctx->d_counts); release(ctx->d_gathered);
+    release(ctx->d_ent_all); release(ctx->d_xcnt); release(ctx->d_xoff); release(ctx->d_xbsum);
+    release(ctx->d_xboff); release(ctx->d_lut_color);
+    if (ctx->h_xtotal) (void)hipHostFree(ctx->h_xtotal);
     if (ctx->h_total) (void)hipHostFree(ctx->h_total);
     if (ctx->h_est) (void)hipHostFree(ctx->h_est);
     release(ctx->d_est);
@@ -416,6 +571,7 @@ int vc_set_grid(vc_ctx *ctx, uint32_t nx, uint32_t ny, uint32_t nz, const double
     VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->have_grid = true;
     ctx->lut_valid = false; ctx->carved = false; ctx->gathered = false; ctx->viewmask_valid = false;
+    ctx->lut_color_cam = -1; ctx->packed = false;
     return VC_OK;
 }
 
@@ -427,6 +583,7 @@ int vc_set_slab(vc_ctx *ctx, uint32_t z0, uint32_t z1)
     if (z0 > z1 || z1 > ctx->nz) return fail(ctx, VC_ERR_ARG, "slab [%u,%u) outside [0,%u]", z0, z1, ctx->nz);
     ctx->z0 = z0; ctx->z1 = z1;
     ctx->lut_valid = false; ctx->carved = false; ctx->gathered = false; ctx->viewmask_valid = false;
+    ctx->packed = false;
     return VC_OK;
 }
 
@@ -473,6 +630,7 @@ int vc_set_cameras(vc_ctx *ctx, uint32_t C, const double *K9, const double *dist
         for (Slot &s : ctx->slots) { release(s.bits); release(s.frames); release(s.grid); s.have_masks = false; s.have_frame.clear(); }
     }
     ctx->lut_valid = false; ctx->carved = false; ctx->gathered = false; ctx->viewmask_valid = false;
+    ctx->lut_color_cam = -1; ctx->packed = false;
     return VC_OK;
 }
 
@@ -641,7 +799,22 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     StepBuf &sb = ctx->sb[ctx->head];
     sb.n = n; sb.survivors = 0; sb.want_vm = want_vm; sb.has_first = false;
     sb.allseen = min_views >= ctx->C;
-    if (n == 0) { sb.pending = true; sb.used = false; ctx->head ^= 1; ctx->npending++; return VC_OK; }
+    sb.no_records = (flags & VC_FLAG_NO_RECORDS) != 0;
+    sb.mode = mode; sb.color_cam = color_cam; sb.slot = slot;
+    // a rank of a communicator packs and exchanges the counts right behind the carve, so that
+    // vc_allgather finds them on the host and only has the payload and the expansion left
+    sb.counts_exchanged = false;
+    const bool auto_exchange = sb.no_records && ctx->comm && ctx->gather_compact;
+    if (n == 0) {
+        if (auto_exchange) {                     // an empty slab still takes part in the collective
+            VC_TRY(enqueue_pack(ctx, sb));
+            VC_TRY(enqueue_counts_exchange(ctx, sb));
+            VC_HIP(ctx, hipEventRecord(sb.e2, ctx->stream));
+            sb.counts_exchanged = true;
+        }
+        sb.pending = true; sb.used = false; ctx->head ^= 1; ctx->npending++;
+        return VC_OK;
+    }
 
     const uint64_t nwords = (n + 63) / 64;
     const uint64_t n_pad = (n + kLutPad - 1) / kLutPad * kLutPad;
@@ -654,7 +827,7 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     VC_TRY(ensure(ctx, sb.blockoff, kMaxScanBlocks + 1));
     VC_TRY(ensure(ctx, ctx->d_est, VC_MAX_CAMERAS));
     if (want_vm) VC_TRY(ensure(ctx, ctx->d_viewmask, n));
-    if (!sb.records.ptr) VC_TRY(ensure(ctx, sb.records, (size_t)(n / 16 + 1024)));
+    if (!sb.records.ptr && !sb.no_records) VC_TRY(ensure(ctx, sb.records, (size_t)(n / 16 + 1024)));
 
     CarveParams p;
     fill_params(ctx, p);
@@ -786,7 +959,12 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     }
     e.records = sb.records.ptr;
     e.capacity = sb.records.cap;
-    VC_TRY(launch_emit(ctx, sb, s2));
+    if (!sb.no_records) VC_TRY(launch_emit(ctx, sb, s2));
+    if (auto_exchange) {
+        VC_TRY(enqueue_pack(ctx, sb));
+        VC_TRY(enqueue_counts_exchange(ctx, sb));
+        sb.counts_exchanged = true;
+    }
     VC_HIP(ctx, hipEventRecord(sb.e2, s2));
     sb.pending = true;
     sb.used = true;
@@ -805,11 +983,11 @@ int vc_carve_end(vc_ctx *ctx, uint64_t *n_out)
     VC_HIP(ctx, hipSetDevice(ctx->device));
     const int k = (ctx->npending == 2) ? ctx->head : (ctx->head ^ 1);      // oldest pending set
     StepBuf &sb = ctx->sb[k];
-    ctx->carved = false; ctx->viewmask_valid = false; ctx->gathered = false;
+    ctx->carved = false; ctx->viewmask_valid = false; ctx->gathered = false; ctx->packed = false;
     if (sb.n != 0) {
         VC_HIP(ctx, hipEventSynchronize(sb.e2));
         uint64_t total = *sb.h_total;
-        if (total > sb.records.cap) {                                      // regrow once, expand again
+        if (!sb.no_records && total > sb.records.cap) {                    // regrow once, expand again
             VC_TRY(ensure(ctx, sb.records, (size_t)(total + total / 8 + 1024)));
             sb.emit.records = sb.records.ptr;
             sb.emit.capacity = sb.records.cap;
@@ -828,6 +1006,7 @@ int vc_carve_end(vc_ctx *ctx, uint64_t *n_out)
         ctx->tm.carve_launches += 1;
         VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.compact_ms, sb.e1, sb.e2));
     } else {
+        if (sb.counts_exchanged) VC_HIP(ctx, hipEventSynchronize(sb.e2));
         sb.survivors = 0;
     }
     sb.pending = false;
@@ -874,6 +1053,8 @@ int vc_fetch_records(vc_ctx *ctx, uint64_t *records)
 {
     if (!ctx || !records) return VC_ERR_ARG;
     if (!ctx->carved) return fail(ctx, VC_ERR_ARG, "no carve result to fetch");
+    if (ctx->sb[ctx->cur].no_records)
+        return fail(ctx, VC_ERR_ARG, "last carve ran with VC_FLAG_NO_RECORDS: use vc_allgather / vc_expand_entries");
     VC_HIP(ctx, hipSetDevice(ctx->device));
     if (ctx->survivors)
         VC_HIP(ctx, hipMemcpy(records, ctx->sb[ctx->cur].records.ptr, ctx->survivors * sizeof(uint64_t), hipMemcpyDeviceToHost));
@@ -926,6 +1107,7 @@ int vc_set_option(vc_ctx *ctx, const char *name, int value)
     else if (k == "lut_hier") ctx->lut_hier = value != 0;
     else if (k == "fused_hier") ctx->fused_hier = value != 0;
     else if (k == "emit_lanes") ctx->emit_lanes = value != 0;
+    else if (k == "gather_compact") ctx->gather_compact = value != 0;
     else if (k == "refine_pair") ctx->refine_pair = value != 0;
     else if (k == "hier_blocks_per_cu" && value >= 1 && value <= 4096) ctx->hier_blocks_per_cu = value;
     else if (k == "first_kv" && (value == 1 || value == 2 || value == 4)) ctx->first_kv = value;
@@ -969,7 +1151,8 @@ int vc_comm_unique_id(uint8_t out[VC_UNIQUE_ID_BYTES])
 int vc_comm_init(vc_ctx *ctx, int n_ranks, int rank, const uint8_t uid[VC_UNIQUE_ID_BYTES])
 {
     if (!ctx || !uid) return VC_ERR_ARG;
-    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(ctx, VC_ERR_ARG, "rank %d of %d", rank, n_ranks);
+    if (n_ranks < 1 || n_ranks > VC_MAX_RANKS || rank < 0 || rank >= n_ranks) return fail(ctx, VC_ERR_ARG, "rank %d of %d", rank, n_ranks);
+    if (ctx->npending) return fail(ctx, VC_ERR_ARG, "carve steps are in flight: collect them with vc_carve_end first");
     std::string err;
     if (!load_rccl(err)) return fail(ctx, VC_ERR_RCCL, "%s", err.c_str());
     VC_HIP(ctx, hipSetDevice(ctx->device));
@@ -997,9 +1180,100 @@ int vc_comm_destroy(vc_ctx *ctx)
     return VC_OK;
 }
 
-// Variable-length all-gather in rank order: counts first (one u64 per rank), then one
-// grouped broadcast per root straight into its displacement of the gathered buffer.  On
-// xGMI every root's chunk leaves over its own links, so the grouped broadcasts overlap.
+// ---- compact exchange form: the slab's non-zero occupancy words ----------------------------------
+int vc_pack_entries(vc_ctx *ctx, uint64_t *n_entries_out)
+{
+    if (!ctx || !n_entries_out) return VC_ERR_ARG;
+    if (!ctx->carved) return fail(ctx, VC_ERR_ARG, "no carve result to pack");
+    VC_HIP(ctx, hipSetDevice(ctx->device));
+    VC_TRY(enqueue_pack(ctx, ctx->sb[ctx->cur]));
+    VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->packed_entries = *ctx->h_xtotal;
+    ctx->packed = true;
+    *n_entries_out = ctx->packed_entries;
+    return VC_OK;
+}
+
+int vc_fetch_entries(vc_ctx *ctx, uint64_t *entries)
+{
+    if (!ctx || !entries) return VC_ERR_ARG;
+    if (!ctx->packed) return fail(ctx, VC_ERR_ARG, "no packed result: call vc_pack_entries");
+    VC_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->packed_entries)
+        VC_HIP(ctx, hipMemcpy(entries, ctx->sb[ctx->cur].ent.ptr, ctx->packed_entries * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return VC_OK;
+}
+
+int vc_expand_entries(vc_ctx *ctx, const uint64_t *entries, uint64_t n_entries, uint64_t *total_out)
+{
+    if (!ctx || !total_out || (!entries && n_entries)) return VC_ERR_ARG;
+    if (!ctx->carved) return fail(ctx, VC_ERR_ARG, "vc_expand_entries colours like the last carve: run one first");
+    if (n_entries > (1ull << 26)) return fail(ctx, VC_ERR_ARG, "%llu entries exceed a u32 grid", (unsigned long long)n_entries);
+    VC_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->gathered = false;
+    VC_TRY(ensure_exchange_scratch(ctx, 1));
+    VC_TRY(ensure(ctx, ctx->d_ent_all, (size_t)(2 * n_entries)));
+    if (n_entries)
+        VC_HIP(ctx, hipMemcpyAsync(ctx->d_ent_all.ptr, entries, n_entries * 2 * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    VC_TRY(enqueue_expand(ctx, ctx->d_ent_all.ptr, n_entries, 0));
+    VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->gathered_total = n_entries ? *(ctx->h_xtotal + 1) : 0;
+    ctx->gathered = true;
+    *total_out = ctx->gathered_total;
+    return VC_OK;
+}
+
+// Compact form of vc_allgather: every rank packs its non-zero words, the {bits, base} pairs are
+// exchanged (~12x fewer bytes over xGMI than the records they stand for at 1024^3), and every rank
+// expands all pairs itself -- colours from its own copy of the colour camera's table and frame.
+static int allgather_compact(vc_ctx *ctx, uint64_t *counts_out, uint64_t *total_out)
+{
+    const int G = ctx->n_ranks;
+    StepBuf &cur = ctx->sb[ctx->cur];
+    VC_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    if (!cur.counts_exchanged) {                 // vc_carve_begin did not do it (records were kept)
+        VC_TRY(enqueue_pack(ctx, cur));
+        VC_TRY(enqueue_counts_exchange(ctx, cur));
+        VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    uint64_t M = 0, S = 0;
+    for (int r = 0; r < G; ++r) { M += cur.h_counts[2 * r]; S += cur.h_counts[2 * r + 1]; }
+    VC_TRY(ensure(ctx, ctx->d_ent_all, (size_t)(2 * M)));
+    VC_TRY(ensure(ctx, cur.ent, 2));
+    VC_NCCL(ctx, g_rccl.GroupStart());
+    uint64_t disp = 0;
+    for (int r = 0; r < G; ++r) {
+        const uint64_t cnt = cur.h_counts[2 * r];
+        if (cnt) {
+            ncclResult_t rc = g_rccl.Broadcast(cur.ent.ptr, ctx->d_ent_all.ptr + 2 * disp, 2 * cnt, ncclUint64, r,
+                                               ctx->comm, ctx->stream);
+            if (rc != ncclSuccess) {
+                g_rccl.GroupEnd();
+                return fail(ctx, VC_ERR_RCCL, "ncclBroadcast(root %d): %s", r, g_rccl.GetErrorString(rc));
+            }
+        }
+        disp += cnt;
+    }
+    VC_NCCL(ctx, g_rccl.GroupEnd());
+    VC_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    if (S) VC_TRY(enqueue_expand(ctx, ctx->d_ent_all.ptr, M, S));
+    VC_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.gather_ms, ctx->ev[0], ctx->ev[1]));
+    VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.exchange_ms, ctx->ev[0], ctx->ev[2]));
+    if (S && *(ctx->h_xtotal + 1) != S)
+        return fail(ctx, VC_ERR_RCCL, "gathered words expand to %llu survivors, the ranks reported %llu",
+                    (unsigned long long)*(ctx->h_xtotal + 1), (unsigned long long)S);
+    if (counts_out) for (int r = 0; r < G; ++r) counts_out[r] = cur.h_counts[2 * r + 1];
+    ctx->gathered_total = S;
+    ctx->gathered = true;
+    *total_out = S;
+    return VC_OK;
+}
+
+// Variable-length all-gather in rank order.  Default (option "gather_compact" = 1): the compact form
+// above.  With the option off: counts first (one u64 per rank), then one grouped broadcast of the
+// 8-byte records per root straight into its displacement of the gathered buffer.
 int vc_allgather(vc_ctx *ctx, uint64_t *counts_out, uint64_t *total_out)
 {
     if (!ctx || !total_out) return VC_ERR_ARG;
@@ -1007,6 +1281,9 @@ int vc_allgather(vc_ctx *ctx, uint64_t *counts_out, uint64_t *total_out)
     if (!ctx->carved) return fail(ctx, VC_ERR_ARG, "no carve result to gather");
     VC_HIP(ctx, hipSetDevice(ctx->device));
     const int G = ctx->n_ranks;
+    if (ctx->gather_compact) return allgather_compact(ctx, counts_out, total_out);
+    if (ctx->sb[ctx->cur].no_records)
+        return fail(ctx, VC_ERR_ARG, "last carve ran with VC_FLAG_NO_RECORDS: the record exchange needs records");
     uint64_t *d_mine = ctx->d_counts.ptr + G;
     *ctx->h_total = ctx->survivors;
     VC_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));

@@ -148,22 +148,24 @@ class CarveEngine:
         return uv
 
     # -- hot path -------------------------------------------------------------------
-    def carve(self, slot=0, min_views=None, color_cam=COLOR_CAMERA_INDEX, mode="fused", viewmask=False):
-        """Runs the carve; returns the survivor count (records stay on the device)."""
+    def carve(self, slot=0, min_views=None, color_cam=COLOR_CAMERA_INDEX, mode="fused", viewmask=False, records=True):
+        """Runs the carve; returns the survivor count (records stay on the device).  records=False keeps
+        only the count and the occupancy words (multi-GPU ranks: allgather() / expand_entries() make the list)."""
         n = ctypes.c_uint64(0)
         mv = self.n_cameras if min_views is None else int(min_views)
         cc = -1 if color_cam is None else int(color_cam)
-        flags = _lib.VC_FLAG_VIEWMASK if viewmask else 0
+        flags = (_lib.VC_FLAG_VIEWMASK if viewmask else 0) | (0 if records else _lib.VC_FLAG_NO_RECORDS)
         self._check(self._L.vc_carve(self._ctx, slot, mv, cc, MODES[mode], flags, ctypes.byref(n)), "vc_carve")
         self.count = int(n.value)
         return self.count
 
-    def carve_begin(self, slot=0, min_views=None, color_cam=COLOR_CAMERA_INDEX, mode="fused", viewmask=False):
+    def carve_begin(self, slot=0, min_views=None, color_cam=COLOR_CAMERA_INDEX, mode="fused", viewmask=False,
+                    records=True):
         """Enqueue a carve step without waiting (at most two in flight), so the device has the next
         step queued while the host collects this one.  carve_end() completes the oldest step."""
         mv = self.n_cameras if min_views is None else int(min_views)
         cc = -1 if color_cam is None else int(color_cam)
-        flags = _lib.VC_FLAG_VIEWMASK if viewmask else 0
+        flags = (_lib.VC_FLAG_VIEWMASK if viewmask else 0) | (0 if records else _lib.VC_FLAG_NO_RECORDS)
         self._check(self._L.vc_carve_begin(self._ctx, slot, mv, cc, MODES[mode], flags), "vc_carve_begin")
 
     def carve_end(self):
@@ -277,6 +279,25 @@ class CarveEngine:
         rec = np.empty(self.gathered_total, dtype=np.uint64)
         self._check(self._L.vc_fetch_gathered(self._ctx, _ptr(rec, ctypes.c_uint64)), "vc_fetch_gathered")
         return rec
+
+    # -- compact exchange form (host-side transports, tests) ---------------------------
+    def pack_entries(self):
+        """The last carve's non-zero occupancy words as u64 [M,2] = {bits, global index of bit 0}, ascending."""
+        m = ctypes.c_uint64(0)
+        self._check(self._L.vc_pack_entries(self._ctx, ctypes.byref(m)), "vc_pack_entries")
+        ent = np.empty((int(m.value), 2), dtype=np.uint64)
+        self._check(self._L.vc_fetch_entries(self._ctx, _ptr(ent, ctypes.c_uint64)), "vc_fetch_entries")
+        return ent
+
+    def expand_entries(self, entries):
+        """All ranks' entries in rank order -> ordered records of the whole grid on this device (read them with
+        fetch_gathered()), coloured like this engine's last carve.  Returns the survivor count."""
+        ent = np.ascontiguousarray(entries, dtype=np.uint64).reshape(-1, 2)
+        total = ctypes.c_uint64(0)
+        self._check(self._L.vc_expand_entries(self._ctx, _ptr(ent, ctypes.c_uint64), ent.shape[0],
+                                              ctypes.byref(total)), "vc_expand_entries")
+        self.gathered_total = int(total.value)
+        return self.gathered_total
 
 
 # -- record / viewer helpers (host arithmetic of assignment.py:127-133) ----------------
