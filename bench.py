@@ -55,6 +55,11 @@ def parse():
                     help="steps in flight: with 2, step i+1 is queued on the device before the host collects step i")
     ap.add_argument("--transport", choices=("rccl", "host"), default="rccl",
                     help="N>1 survivor exchange: rccl (device, default) or host (gloo; rehearsal on one GPU)")
+    ap.add_argument("--exchange", choices=("compact", "records"), default="compact",
+                    help="N>1 over RCCL: exchange the non-zero occupancy words and expand on every rank (default), "
+                         "or the 8-byte survivor records themselves")
+    ap.add_argument("--split", choices=("balanced", "even"), default="balanced",
+                    help="N>1: z-slab boundaries from the measured cost of every 16-layer chunk (default) or nz/N layers each")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     ap.add_argument("--force-comm", action="store_true",
                     help="rehearsal: take the N > 1 path (file rendezvous, RCCL communicator, all-gather per step) even with one rank")
@@ -122,13 +127,16 @@ class Group:
             self.shm.close()
 
 
-def run_mode(eng, grp, mode, steps, warmup, multi, host_transport=None, depth=2):
+def run_mode(eng, grp, mode, steps, warmup, multi, host_transport=None, depth=2, exchange="compact"):
     """W untimed + K timed steps of one mode; returns (seconds, kernel ms avg, survivors, total)."""
     eng.set_option("lut_hier", 0 if mode == "lut_stream" else 1)
     mode = "lut" if mode == "lut_stream" else mode
 
     def finish():
         n = eng.carve_end()
+        if multi and host_transport is not None and exchange == "compact":
+            # host rehearsal / fallback: the compact form through host memory, expanded on the device
+            return n, eng.expand_entries(host_transport.allgather_entries(eng.pack_entries()))
         if multi and host_transport is not None:
             _, total = host_transport.allgather_records(eng.fetch_records(pinned=True))
             return n, total
@@ -137,18 +145,25 @@ def run_mode(eng, grp, mode, steps, warmup, multi, host_transport=None, depth=2)
             return n, total
         return n, n
 
+    # a rank of a communicator never reads its own slab's list: the records come out of the all-gather
+    keep = not (multi and exchange == "compact")
+    eng.set_option("gather_compact", 1 if exchange == "compact" else 0)
+    # the all-gather of step i is only queued (its count is known from the ranks' counts); the next step is
+    # enqueued behind it without a host round trip; synchronize() closes the timed region
+    eng.set_option("gather_sync", 0 if (not keep and depth > 1 and host_transport is None) else 1)
+
     def run(first, count):
         """`count` steps; with depth 2 step i+1 is enqueued before step i is collected, so the device
         never idles between steps (one stream, same kernels)."""
         last = (0, 0)
         if depth <= 1:
             for i in range(count):
-                eng.carve_begin(slot=(first + i) % N_SLOTS, mode=mode)
+                eng.carve_begin(slot=(first + i) % N_SLOTS, mode=mode, records=keep)
                 last = finish()
             return last
-        eng.carve_begin(slot=first % N_SLOTS, mode=mode)
+        eng.carve_begin(slot=first % N_SLOTS, mode=mode, records=keep)
         for i in range(1, count):
-            eng.carve_begin(slot=(first + i) % N_SLOTS, mode=mode)
+            eng.carve_begin(slot=(first + i) % N_SLOTS, mode=mode, records=keep)
             last = finish()
         return finish()
 
@@ -220,7 +235,8 @@ def main():
         eng.upload_frame(1, np.roll(frames[1], 3 * s, axis=1), slot=s)
     multi = grp.world > 1 or args.force_comm
     host_transport = None
-    transport_note = "rccl" if multi else "none (one rank)"
+    transport_note = ("rccl, %s" % ("non-zero occupancy words, expanded on every rank" if args.exchange == "compact"
+                                    else "8-byte survivor records")) if multi else "none (one rank)"
     if multi and args.transport == "host":
         host_transport = slabs.TorchTransport()
         transport_note = "host (gloo) rehearsal"
@@ -236,6 +252,15 @@ def main():
             sys.stderr.write("[bench rank %d] %s\n" % (grp.rank, transport_note))
             host_transport = slabs.ShmTransport(grp.world, grp.rank)
             grp.attach_fallback(host_transport)
+    split_note = "even"
+    if grp.world > 1 and args.split == "balanced":
+        # the hull is not spread evenly over z: give every rank the same share of measured kernel time
+        chunk = 16
+        weights = slabs.measure_chunk_cost(eng, G, chunk, reduce_max=grp.max)
+        bounds = slabs.balanced_bounds(weights, chunk, G, grp.world)
+        z0, z1 = bounds[grp.rank], bounds[grp.rank + 1]
+        split_note = "balanced by measured chunk cost: z bounds %s" % bounds
+    eng.set_slab(z0, z1)
     prep_ms = eng.timing()["h2d_ms"]          # last frame set: H2D of the byte masks + post-filter + bit-pack + block grid
     eng.build_lut()
     lut_ms = eng.timing()["lut_ms"]
@@ -246,9 +271,10 @@ def main():
     results = {}
     order = [args.mode] + [m for m in ("lut", "lut_stream", "fused") if m != args.mode]
     for mode in order:
-        dt, kernel_ms, n_local, n_total, tm = run_mode(eng, grp, mode, args.steps, args.warmup, multi, host_transport, args.depth)
+        dt, kernel_ms, n_local, n_total, tm = run_mode(eng, grp, mode, args.steps, args.warmup, multi, host_transport, args.depth, args.exchange)
         results[mode] = {"seconds": dt, "kernel_ms": kernel_ms, "survivors": int(n_total),
-                         "compact_ms": tm["compact_ms"], "gather_ms": tm["gather_ms"], "tm": tm}
+                         "compact_ms": tm["compact_ms"], "gather_ms": tm["gather_ms_sum"] / max(1, tm["gathers"]),
+                         "exchange_ms": tm["exchange_ms"], "tm": tm}
 
     n_local_vox = eng.n_voxels
     total_vv = float(G) ** 3 * C
@@ -320,12 +346,13 @@ def main():
                                "ordered survivor list + colour%s" % (G, C, W, H, grp.world, args.mode,
                                                                      (" + RCCL all-gather" if host_transport is None else " + host-side gather") if multi else ""),
                    "grid": [G, G, G], "cameras": C, "mode": args.mode, "survivors": head["survivors"],
-                   "steps_in_flight": args.depth, "exchange": transport_note},
+                   "steps_in_flight": args.depth, "exchange": transport_note, "split": split_note},
         "roofline": roof,
         "roofline_stream": roof_stream,
         "other_modes": others,
         "phases_ms": {"carve_kernels": round(head["kernel_ms"], 4), "compact": round(head["compact_ms"], 4),
-                      "gather": round(head["gather_ms"], 4), "lut_build_once": round(lut_ms, 3),
+                      "gather": round(head["gather_ms"], 4), "gather_exchange_part": round(head["exchange_ms"], 4),
+                      "lut_build_once": round(lut_ms, 3),
                       "frame_set_upload_and_prep": round(prep_ms, 4)},
     }
     if args.e2e and grp.world == 1:

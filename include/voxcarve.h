@@ -64,6 +64,8 @@ typedef struct {
     float first_ms;     /* VC_MODE_LUT: the first-camera streaming kernel of the last carve */
     float first_ms_sum; /* summed since vc_timing_reset                                 */
     float exchange_ms;  /* vc_allgather, compact form: pack + RCCL part of gather_ms         */
+    float gather_ms_sum; /* summed since vc_timing_reset                                */
+    uint32_t gathers;   /* vc_allgather calls since vc_timing_reset                      */
 } vc_timing_t;
 
 /* ---- lifetime ------------------------------------------------------------------ */

@@ -415,6 +415,7 @@ def test_rccl_allgather_single_rank(eng, cams, masks, frames):
             eng.carve(slot=slot, mode=mode)
             want.append(eng.fetch_records())
         got = []
+        eng.set_option("gather_sync", 1 if mode == "lut" else 0)      # 0: allgather() returns once its work is queued
         eng.carve_begin(slot=0, mode=mode, records=False)
         for slot in (1, 1, 0):
             eng.carve_begin(slot=slot, mode=mode, records=False)
@@ -427,6 +428,7 @@ def test_rccl_allgather_single_rank(eng, cams, masks, frames):
         got.append(eng.fetch_gathered())
         for a, b in zip(got, want):
             assert np.array_equal(a, b), mode
+    eng.set_option("gather_sync", 1)
     eng.comm_destroy()
 
 

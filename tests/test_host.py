@@ -122,3 +122,25 @@ def test_synthetic_scene_is_deterministic_and_centred():
     m2 = synthetic.ellipsoid_masks(synthetic.ring_cameras(4, 486, 644), 486, 644)
     assert all(np.array_equal(a, b) for a, b in zip(m1, m2))
     assert all(0.02 < (m > 0).mean() < 0.08 for m in m1)
+
+
+def test_balanced_slab_bounds():
+    """Work-balanced contiguous z-split: ascending, covers [0, nz], chunk-aligned, even shares for even weights,
+    follows the weight when the hull sits in a few layers, degenerate inputs."""
+    from voxcarve import slabs
+    assert slabs.balanced_bounds([1.0] * 8, 16, 128, 4) == [0, 32, 64, 96, 128]
+    assert slabs.balanced_bounds([0.0] * 8, 16, 128, 4) == [0, 32, 64, 96, 128]          # nothing measured: even split
+    b = slabs.balanced_bounds([0, 0, 1, 5, 9, 3, 1, 0], 16, 128, 4)
+    assert b[0] == 0 and b[-1] == 128 and b == sorted(b) and all(x % 16 == 0 for x in b)
+    w = np.array([0, 0, 1, 5, 9, 3, 1, 0], float)
+    shares = [w[b[r] // 16:b[r + 1] // 16].sum() for r in range(4)]
+    assert max(shares) <= 9.0                                # no rank worse than the one indivisible chunk
+    assert slabs.balanced_bounds([3.0], 16, 10, 3)[-1] == 10          # fewer chunks than ranks: empty slabs
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        nz = int(rng.integers(1, 300)); chunk = int(rng.integers(1, 40)); G = int(rng.integers(1, 9))
+        w = rng.random((nz + chunk - 1) // chunk) * (rng.random((nz + chunk - 1) // chunk) > 0.3)
+        b = slabs.balanced_bounds(w, chunk, nz, G)
+        assert len(b) == G + 1 and b[0] == 0 and b[-1] == nz and all(b[i] <= b[i + 1] for i in range(G))
+    with pytest.raises(ValueError):
+        slabs.balanced_bounds([1.0, 2.0], 16, 128, 4)

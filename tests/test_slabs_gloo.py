@@ -19,6 +19,24 @@ def _free_port():
     return port
 
 
+def _entries_from_indices(idx, i0):
+    """Host restatement of vc_pack_entries: non-zero 64-voxel words of a slab starting at global index i0."""
+    local = idx.astype(np.int64) - i0
+    w = local >> 6
+    words, inv = np.unique(w, return_inverse=True)
+    bits = np.zeros(words.size, np.uint64)
+    np.bitwise_or.at(bits, inv, np.uint64(1) << (local & 63).astype(np.uint64))
+    return np.stack([bits, (words * 64 + i0).astype(np.uint64)], axis=1)
+
+
+def _indices_from_entries(ent):
+    out = []
+    for bits, base in ent:
+        b = int(bits)
+        out.extend(int(base) + k for k in range(64) if (b >> k) & 1)
+    return np.array(out, dtype=np.uint32)
+
+
 def _worker(rank, world, port, grid, out_dir):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -38,6 +56,9 @@ def _worker(rank, world, port, grid, out_dir):
         assert int(counts[rank]) == rec.size
         np.save(os.path.join(out_dir, "gathered_%d.npy" % rank), tr.fetch())
         np.save(os.path.join(out_dir, "counts_%d.npy" % rank), counts)
+        # the compact exchange form over the same transport (what bench.py --transport host moves)
+        ent = tr.allgather_entries(_entries_from_indices(res["idx"], i0))
+        np.save(os.path.join(out_dir, "entries_%d.npy" % rank), ent)
     finally:
         dist.destroy_process_group()
 
@@ -58,6 +79,10 @@ def test_slab_split_allgather_equals_single_rank(built, tmp_path, world, grid):
         assert int(np.load(tmp_path / ("counts_%d.npy" % r)).sum()) == full["count"]
     idx, rgb, seen = unpack_records(first)
     assert np.array_equal(idx, full["idx"]) and np.array_equal(rgb[:, ::-1], full["bgr"]) and seen.all()
+    ent0 = np.load(tmp_path / "entries_0.npy")
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / ("entries_%d.npy" % r)), ent0)
+    assert np.array_equal(_indices_from_entries(ent0), full["idx"])
 
 
 def _shm_worker(rank, world, port, out_dir):
@@ -72,6 +97,8 @@ def _shm_worker(rank, world, port, out_dir):
             got = tr.fetch()
             want = np.concatenate([np.arange(5 + r + rnd, dtype=np.uint64) + 1000 * r + 1 for r in range(world)])
             assert np.array_equal(got, want)
+        ent = tr.allgather_entries(np.array([[3, 64 * (10 * rank + 1)], [1 << 63, 64 * (10 * rank + 2)]], np.uint64))
+        assert ent.shape == (2 * world, 2) and ent[:, 1].tolist() == sorted(ent[:, 1].tolist())
         assert tr.max(float(rank)) == float(world - 1)
         tr.barrier()
         np.save(os.path.join(out_dir, "ok_%d.npy" % rank), np.array([1]))

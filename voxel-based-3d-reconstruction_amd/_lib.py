@@ -35,7 +35,8 @@ class VcTiming(ctypes.Structure):
                 ("h2d_ms", ctypes.c_float), ("voxels", ctypes.c_uint64),
                 ("survivors", ctypes.c_uint64), ("carve_launches", ctypes.c_uint32),
                 ("carve_ms_sum", ctypes.c_float), ("first_ms", ctypes.c_float),
-                ("first_ms_sum", ctypes.c_float), ("exchange_ms", ctypes.c_float)]
+                ("first_ms_sum", ctypes.c_float), ("exchange_ms", ctypes.c_float),
+                ("gather_ms_sum", ctypes.c_float), ("gathers", ctypes.c_uint32)]
 
 
 # name -> (restype, argtypes); every symbol include/voxcarve.h declares.

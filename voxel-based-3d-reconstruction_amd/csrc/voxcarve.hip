@@ -196,6 +196,9 @@ struct vc_ctx {
     bool gathered = false;
     // compact exchange: non-zero words of the slab as {bits, global index of bit 0} pairs
     int gather_compact = 1;          // vc_allgather exchanges the pairs and expands them on every rank
+    int gather_sync = 1;             // 0: vc_allgather returns once its work is queued (count known from the ranks' counts)
+    bool gather_pending = false;     // a queued all-gather whose completion has not been observed yet
+    uint64_t gather_expect = 0;
     DevBuf<uint64_t> d_ent_all;              // all ranks' pairs in rank order
     DevBuf<uint32_t> d_xcnt, d_xoff;         // scan scratch of the pack and expand passes (stream-ordered)
     DevBuf<uint64_t> d_xbsum, d_xboff;
@@ -405,6 +408,23 @@ int ensure_color_table(vc_ctx *ctx, int cam)
     return VC_OK;
 }
 
+// Observes the completion of a queued all-gather: its timing, and that the expansion produced
+// the survivor count the ranks announced.
+int finish_gather(vc_ctx *ctx)
+{
+    if (!ctx->gather_pending) return VC_OK;
+    ctx->gather_pending = false;
+    VC_HIP(ctx, hipEventSynchronize(ctx->ev[1]));
+    VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.gather_ms, ctx->ev[0], ctx->ev[1]));
+    VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.exchange_ms, ctx->ev[0], ctx->ev[2]));
+    ctx->tm.gather_ms_sum += ctx->tm.gather_ms;
+    ctx->tm.gathers += 1;
+    if (ctx->gather_expect && *(ctx->h_xtotal + 1) != ctx->gather_expect)
+        return fail(ctx, VC_ERR_RCCL, "gathered words expand to %llu survivors, the ranks reported %llu",
+                    (unsigned long long)*(ctx->h_xtotal + 1), (unsigned long long)ctx->gather_expect);
+    return VC_OK;
+}
+
 // Expands M gathered entries (device, ascending) into the ordered survivor records of the whole grid
 // in ctx->d_gathered, coloured the way the current step was (its mode, colour camera and frame set).
 // S_hint = expected survivor count (0 = unknown: sized after a host synchronisation).
@@ -547,7 +567,7 @@ int vc_synchronize(vc_ctx *ctx)
 {
     if (!ctx) return VC_ERR_ARG;
     VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return VC_OK;
+    return finish_gather(ctx);
 }
 
 int vc_set_grid(vc_ctx *ctx, uint32_t nx, uint32_t ny, uint32_t nz, const double bounds[6])
@@ -1108,6 +1128,7 @@ int vc_set_option(vc_ctx *ctx, const char *name, int value)
     else if (k == "fused_hier") ctx->fused_hier = value != 0;
     else if (k == "emit_lanes") ctx->emit_lanes = value != 0;
     else if (k == "gather_compact") ctx->gather_compact = value != 0;
+    else if (k == "gather_sync") ctx->gather_sync = value != 0;
     else if (k == "refine_pair") ctx->refine_pair = value != 0;
     else if (k == "hier_blocks_per_cu" && value >= 1 && value <= 4096) ctx->hier_blocks_per_cu = value;
     else if (k == "first_kv" && (value == 1 || value == 2 || value == 4)) ctx->first_kv = value;
@@ -1122,6 +1143,7 @@ int vc_set_option(vc_ctx *ctx, const char *name, int value)
 int vc_timing(vc_ctx *ctx, vc_timing_t *out)
 {
     if (!ctx || !out) return VC_ERR_ARG;
+    VC_TRY(finish_gather(ctx));
     *out = ctx->tm;
     return VC_OK;
 }
@@ -1132,6 +1154,8 @@ int vc_timing_reset(vc_ctx *ctx)
     ctx->tm.carve_launches = 0;
     ctx->tm.carve_ms_sum = 0;
     ctx->tm.first_ms_sum = 0;
+    ctx->tm.gather_ms_sum = 0;
+    ctx->tm.gathers = 0;
     return VC_OK;
 }
 
@@ -1173,6 +1197,8 @@ int vc_comm_destroy(vc_ctx *ctx)
     if (!ctx) return VC_ERR_ARG;
     if (ctx->comm) {
         (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        ctx->gather_pending = false;
         VC_NCCL(ctx, g_rccl.CommDestroy(ctx->comm));
         ctx->comm = nullptr;
     }
@@ -1210,6 +1236,7 @@ int vc_expand_entries(vc_ctx *ctx, const uint64_t *entries, uint64_t n_entries, 
     if (!ctx->carved) return fail(ctx, VC_ERR_ARG, "vc_expand_entries colours like the last carve: run one first");
     if (n_entries > (1ull << 26)) return fail(ctx, VC_ERR_ARG, "%llu entries exceed a u32 grid", (unsigned long long)n_entries);
     VC_HIP(ctx, hipSetDevice(ctx->device));
+    VC_TRY(finish_gather(ctx));
     ctx->gathered = false;
     VC_TRY(ensure_exchange_scratch(ctx, 1));
     VC_TRY(ensure(ctx, ctx->d_ent_all, (size_t)(2 * n_entries)));
@@ -1230,6 +1257,7 @@ static int allgather_compact(vc_ctx *ctx, uint64_t *counts_out, uint64_t *total_
 {
     const int G = ctx->n_ranks;
     StepBuf &cur = ctx->sb[ctx->cur];
+    VC_TRY(finish_gather(ctx));
     VC_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     if (!cur.counts_exchanged) {                 // vc_carve_begin did not do it (records were kept)
         VC_TRY(enqueue_pack(ctx, cur));
@@ -1258,16 +1286,13 @@ static int allgather_compact(vc_ctx *ctx, uint64_t *counts_out, uint64_t *total_
     VC_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     if (S) VC_TRY(enqueue_expand(ctx, ctx->d_ent_all.ptr, M, S));
     VC_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-    VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.gather_ms, ctx->ev[0], ctx->ev[1]));
-    VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.exchange_ms, ctx->ev[0], ctx->ev[2]));
-    if (S && *(ctx->h_xtotal + 1) != S)
-        return fail(ctx, VC_ERR_RCCL, "gathered words expand to %llu survivors, the ranks reported %llu",
-                    (unsigned long long)*(ctx->h_xtotal + 1), (unsigned long long)S);
+    ctx->gather_pending = true;
+    ctx->gather_expect = S;
     if (counts_out) for (int r = 0; r < G; ++r) counts_out[r] = cur.h_counts[2 * r + 1];
     ctx->gathered_total = S;
     ctx->gathered = true;
     *total_out = S;
+    if (ctx->gather_sync) VC_TRY(finish_gather(ctx));
     return VC_OK;
 }
 
@@ -1282,6 +1307,7 @@ int vc_allgather(vc_ctx *ctx, uint64_t *counts_out, uint64_t *total_out)
     VC_HIP(ctx, hipSetDevice(ctx->device));
     const int G = ctx->n_ranks;
     if (ctx->gather_compact) return allgather_compact(ctx, counts_out, total_out);
+    VC_TRY(finish_gather(ctx));
     if (ctx->sb[ctx->cur].no_records)
         return fail(ctx, VC_ERR_ARG, "last carve ran with VC_FLAG_NO_RECORDS: the record exchange needs records");
     uint64_t *d_mine = ctx->d_counts.ptr + G;
@@ -1314,6 +1340,9 @@ int vc_allgather(vc_ctx *ctx, uint64_t *counts_out, uint64_t *total_out)
     VC_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.gather_ms, ctx->ev[0], ctx->ev[1]));
+    ctx->tm.exchange_ms = ctx->tm.gather_ms;
+    ctx->tm.gather_ms_sum += ctx->tm.gather_ms;
+    ctx->tm.gathers += 1;
     if (counts_out) memcpy(counts_out, ctx->h_counts, sizeof(uint64_t) * G);
     ctx->gathered_total = total;
     ctx->gathered = true;
@@ -1342,6 +1371,7 @@ int vc_fetch_gathered(vc_ctx *ctx, uint64_t *records)
     if (!ctx || !records) return VC_ERR_ARG;
     if (!ctx->gathered) return fail(ctx, VC_ERR_ARG, "no gathered result: call vc_allgather");
     VC_HIP(ctx, hipSetDevice(ctx->device));
+    VC_TRY(finish_gather(ctx));
     if (ctx->gathered_total)
         VC_HIP(ctx, hipMemcpy(records, ctx->d_gathered.ptr, ctx->gathered_total * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return VC_OK;

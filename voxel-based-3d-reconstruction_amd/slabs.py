@@ -30,6 +30,57 @@ def slab_index_range(grid, n_ranks, rank):
     return z0 * nx * ny, z1 * nx * ny
 
 
+def balanced_bounds(weights, chunk, nz, n_ranks):
+    """Slab boundaries [b_0 = 0, ..., b_G = nz] at multiples of ``chunk`` layers so that every rank gets about
+    the same share of ``weights`` (cost of each chunk of z-layers: the hull is not spread evenly over z, and
+    the hierarchical kernel's time follows the undecided words, not the voxel count).  Contiguous and
+    ascending, so the rank-ordered concatenation stays the reference order.  Deterministic in its inputs:
+    every rank must pass the same weights (share them with a max-reduction)."""
+    w = np.maximum(np.asarray(weights, dtype=np.float64), 0.0)
+    nchunks = (nz + chunk - 1) // chunk
+    if w.size != nchunks:
+        raise ValueError("%d weights for %d chunks" % (w.size, nchunks))
+    if n_ranks < 1:
+        raise ValueError("n_ranks %d" % n_ranks)
+    total = float(w.sum())
+    if total <= 0.0:
+        return [(r * nz) // n_ranks for r in range(n_ranks + 1)]
+    cum = np.concatenate([[0.0], np.cumsum(w)])
+    bounds = [0]
+    for r in range(1, n_ranks):
+        target = total * r / n_ranks
+        k = int(np.searchsorted(cum, target))              # first chunk edge at or past the target
+        if k > 0 and target - cum[k - 1] < cum[min(k, nchunks)] - target:
+            k -= 1                                          # the nearer edge
+        k = max(k, 0)
+        z = min(k * chunk, nz)
+        bounds.append(max(z, bounds[-1]))
+    bounds.append(nz)
+    return bounds
+
+
+def measure_chunk_cost(engine, nz, chunk, mode="lut", repeats=5, reduce_max=None, **carve_kwargs):
+    """Kernel time of the carve on every chunk of ``chunk`` z-layers (current masks of slot 0), in ms.
+    ``reduce_max`` (e.g. engine.comm_max) makes the figures identical on every rank."""
+    out = []
+    for z in range(0, nz, chunk):
+        engine.set_slab(z, min(z + chunk, nz))
+        if mode == "lut":
+            engine.build_lut()
+        for _ in range(2):
+            engine.carve(mode=mode, records=False, **carve_kwargs)
+        engine.timing(reset=True)
+        for _ in range(repeats):
+            engine.carve(mode=mode, records=False, **carve_kwargs)
+        tm = engine.timing()
+        out.append(tm["carve_ms_sum"] / max(1, tm["carve_launches"]))
+    floor = 0.6 * min(out)                                  # most of an empty chunk's time is launch + start-up
+    out = [max(t - floor, 1e-4) for t in out]
+    if reduce_max is not None:
+        out = [reduce_max(t) for t in out]
+    return out
+
+
 def merge_rank_lists(per_rank_records):
     """Concatenate per-rank record arrays in rank order and verify global ascending order."""
     parts = [np.ascontiguousarray(p, dtype=np.uint64) for p in per_rank_records]
@@ -37,6 +88,17 @@ def merge_rank_lists(per_rank_records):
     idx = out.astype(np.uint32)
     if idx.size > 1 and not np.all(idx[1:] > idx[:-1]):
         raise RuntimeError("gathered survivor list is not strictly ascending: slabs overlap or are misordered")
+    return out
+
+
+def merge_rank_entries(per_rank_entries):
+    """Concatenate per-rank {bits, base} entry arrays ([M_r, 2] u64, vc_pack_entries) in rank order and verify
+    that the words ascend -- the form vc_expand_entries takes."""
+    parts = [np.ascontiguousarray(p, dtype=np.uint64).reshape(-1, 2) for p in per_rank_entries]
+    out = np.concatenate(parts) if parts else np.empty((0, 2), np.uint64)
+    base = out[:, 1].astype(np.int64)
+    if base.size > 1 and not np.all(base[1:] >= base[:-1] + 64):
+        raise RuntimeError("gathered occupancy words overlap or are misordered")
     return out
 
 
@@ -65,9 +127,19 @@ class TorchTransport:
         self._gathered = None
 
     def allgather_records(self, local_records):
+        parts = self._parts(local_records)
+        self._gathered = merge_rank_lists(parts)
+        counts = np.array([p.size for p in parts], dtype=np.uint64)
+        return counts, int(self._gathered.size)
+
+    def allgather_entries(self, local_entries):
+        """Host exchange of the compact form: returns all ranks' entries [M, 2] for engine.expand_entries."""
+        return merge_rank_entries(self._parts(np.ascontiguousarray(local_entries, dtype=np.uint64).ravel()))
+
+    def _parts(self, local_u64):
         torch, dist = self._torch, self._dist
         world = dist.get_world_size(self._group)
-        local = np.ascontiguousarray(local_records, dtype=np.uint64)
+        local = np.ascontiguousarray(local_u64, dtype=np.uint64)
         counts_t = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
         dist.all_gather(counts_t, torch.tensor([local.size], dtype=torch.int64), group=self._group)
         counts = np.array([int(t.item()) for t in counts_t], dtype=np.uint64)
@@ -76,9 +148,7 @@ class TorchTransport:
         send[:local.size] = torch.from_numpy(local.view(np.int64).copy())
         recv = [torch.zeros(max(cap, 1), dtype=torch.int64) for _ in range(world)]
         dist.all_gather(recv, send, group=self._group)
-        parts = [recv[r][:int(counts[r])].numpy().view(np.uint64) for r in range(world)]
-        self._gathered = merge_rank_lists(parts)
-        return counts, int(counts.sum())
+        return [recv[r][:int(counts[r])].numpy().view(np.uint64) for r in range(world)]
 
     def fetch(self):
         return self._gathered
@@ -149,10 +219,20 @@ class ShmTransport:
             time.sleep(0.0005)
 
     def allgather_records(self, local_records):
+        parts = self._parts(local_records)
+        self._gathered = merge_rank_lists(parts)
+        counts = np.array([p.size for p in parts], dtype=np.uint64)
+        return counts, int(counts.sum())
+
+    def allgather_entries(self, local_entries):
+        """Host exchange of the compact form: returns all ranks' entries [M, 2] for engine.expand_entries."""
+        return merge_rank_entries(self._parts(np.ascontiguousarray(local_entries, dtype=np.uint64).ravel()))
+
+    def _parts(self, local_u64):
         import os
         rnd = self.round
         self.round += 1
-        local = np.ascontiguousarray(local_records, dtype=np.uint64)
+        local = np.ascontiguousarray(local_u64, dtype=np.uint64)
         tmp = self._path(rnd, self.rank, "tmp")
         np.save(tmp, local)
         os.replace(tmp, self._path(rnd, self.rank, "rec"))
@@ -161,7 +241,6 @@ class ShmTransport:
             path = self._path(rnd, r, "rec")
             self._wait(path)
             parts.append(local if r == self.rank else np.load(path))
-        self._gathered = merge_rank_lists(parts)
         # everyone has read round rnd once all ranks have posted their "done" marker; then remove own file
         open(self._path(rnd, self.rank, "done"), "w").close()
         for r in range(self.n_ranks):
@@ -172,11 +251,10 @@ class ShmTransport:
                     os.remove(self._path(rnd - 1, self.rank, kind))
                 except OSError:
                     pass
-        counts = np.array([p.size for p in parts], dtype=np.uint64)
-        return counts, int(counts.sum())
+        return parts
 
     def barrier(self):
-        self.allgather_records(np.empty(0, np.uint64))
+        self._parts(np.empty(0, np.uint64))
 
     def max(self, x):
         import os
