@@ -471,6 +471,12 @@ def test_set_voxel_positions_drop_in(built, cams, masks, frames):
         assert pos.dtype == np.float32 and pos.shape == (len(data), 3) and len(pos) == len(col)
         assert np.array_equal(pos, np.array(data, dtype=np.float32))      # what mesh.py:82 would build
         assert np.array_equal(col, np.array(cols, dtype=np.float32))
+        # dense ON/OFF volume in the shape the reference feeds to marching cubes (assignment.py:143-146)
+        from oracle import carve_c
+        want = np.zeros(32 * 32 * 32, bool)
+        want[carve_c.carve(32, 32, 32, fx.oracle_cams(file_cams), masks, frames)["idx"]] = True
+        status = assignment.voxels_status()
+        assert status.shape == (32, 32, 32) and np.array_equal(status, want.reshape(32, 32, 32))
         assert assignment.set_voxel_positions(32, 16, 32) == ([], [])     # end of video
     assignment.configure(frame_source=src)
     del src
@@ -516,12 +522,23 @@ def test_full_size_1024_properties(eng, cams, masks, frames):
         sel = (idx >= i0) & (idx < i1)
         assert np.array_equal(idx[sel], want["idx"])
         assert np.array_equal(rec[sel].view(np.uint8).reshape(-1, 8)[:, 4:7][:, ::-1], want["bgr"])
-    # 8-way slab split (BASELINE config 4) concatenates to the same list
-    parts = []
+    # 8-way slab split (BASELINE config 4) concatenates to the same list -- as records, and in the compact
+    # form the ranks exchange (non-zero occupancy words, expanded on one device; uneven work-balanced bounds)
+    parts, ents = [], []
+    bounds = [0, 272, 384, 496, 592, 672, 736, 832, 1024]
     for r in range(8):
         slabs.carve_slab(eng, grid, 8, r)
         parts.append(eng.fetch_records())
     assert hashlib.sha256(slabs.merge_rank_lists(parts).tobytes()).hexdigest() == digest
+    del parts
+    for r in range(8):
+        eng.set_slab(bounds[r], bounds[r + 1])
+        eng.carve(mode="fused", records=False)
+        ents.append(eng.pack_entries())
+    allent = slabs.merge_rank_entries(ents)
+    assert allent.shape[0] * 16 * 10 < rec.size * 8                     # > 10x fewer bytes than the records
+    assert eng.expand_entries(allent) == n
+    assert hashlib.sha256(eng.fetch_gathered().tobytes()).hexdigest() == digest
     # LUT mode on one slab (the table for the whole grid is 17 GB; a quarter is plenty here)
     eng.set_slab(256, 512)
     eng.build_lut()

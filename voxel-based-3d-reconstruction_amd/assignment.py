@@ -143,3 +143,15 @@ def set_voxel_positions(width, height, depth):
     idx, rgb, _ = _engine.fetch()
     keys = voxel_keys(idx, _engine.grid, _engine.axes())
     return viewer_positions(keys), viewer_colors(rgb)
+
+
+def voxels_status():
+    """Dense ON/OFF volume of the last set_voxel_positions call, shaped (width, height*2, depth) exactly as the
+    reference builds it for voxel_reconstruction.plot_marching_cubes (assignment.py:143-146: the list of
+    statuses in lookup-table order, reshaped): feed it to skimage.measure.marching_cubes as the reference does.
+    The bits come straight off the device (vc_fetch_occupancy), no pass over Python dicts."""
+    if _engine is None or not initialized:
+        raise RuntimeError("set_voxel_positions has not run")
+    nx, ny, nz = _engine.grid
+    return _engine.fetch_occupancy().reshape(nx, ny, nz)
+

@@ -443,7 +443,8 @@ int enqueue_expand(vc_ctx *ctx, const uint64_t *d_entries, uint64_t M, uint64_t 
         VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
         S_hint = *(ctx->h_xtotal + 1);
     }
-    VC_TRY(ensure(ctx, ctx->d_gathered, (size_t)S_hint));
+    if (S_hint > ctx->d_gathered.cap)            // survivor counts drift from frame to frame: grow with slack
+        VC_TRY(ensure(ctx, ctx->d_gathered, (size_t)(S_hint + S_hint / 8 + 1024)));
     EmitParams e;                                // axes, camera, mask bits and frame of the step
     memset(&e, 0, sizeof e);
     e.xs = ctx->d_axes.ptr; e.ys = e.xs + ctx->nx; e.zs = e.ys + ctx->ny;
@@ -1266,7 +1267,7 @@ static int allgather_compact(vc_ctx *ctx, uint64_t *counts_out, uint64_t *total_
     }
     uint64_t M = 0, S = 0;
     for (int r = 0; r < G; ++r) { M += cur.h_counts[2 * r]; S += cur.h_counts[2 * r + 1]; }
-    VC_TRY(ensure(ctx, ctx->d_ent_all, (size_t)(2 * M)));
+    if (2 * M > ctx->d_ent_all.cap) VC_TRY(ensure(ctx, ctx->d_ent_all, (size_t)(2 * M + M / 4 + 1024)));
     VC_TRY(ensure(ctx, cur.ent, 2));
     VC_NCCL(ctx, g_rccl.GroupStart());
     uint64_t disp = 0;
