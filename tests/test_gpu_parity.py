@@ -499,6 +499,22 @@ def test_error_paths_raise(eng, cams, masks):
         eng.set_slab(3, 99)
     with pytest.raises(ValueError):
         eng.upload_masks(masks[:2])
+    # compact exchange form: needs a carve result; a reconfiguration invalidates it
+    eng.set_grid(8, 8, 8)
+    with pytest.raises(VoxcarveError, match="no carve result"):
+        eng.pack_entries()
+    with pytest.raises(VoxcarveError, match="last carve"):
+        eng.expand_entries(np.zeros((1, 2), np.uint64))
+    with pytest.raises(VoxcarveError, match="vc_comm_init"):
+        eng.allgather()
+    eng.carve(mode="fused", records=False)
+    with pytest.raises(VoxcarveError, match="NO_RECORDS"):
+        eng.fetch()
+    ent = eng.pack_entries()
+    assert eng.expand_entries(ent) == eng.count
+    eng.set_slab(0, 4)
+    with pytest.raises(VoxcarveError, match="no gathered result|no carve result"):
+        eng.pack_entries()
 
 
 def test_full_size_1024_properties(eng, cams, masks, frames):
