@@ -45,7 +45,10 @@ typedef enum {
 enum {
     VC_FLAG_VIEWMASK = 1u,   /* also keep the per-voxel camera bitmask (compat dicts) */
     VC_FLAG_NO_RECORDS = 2u  /* count + occupancy only: the records are produced by vc_allgather /
-                                vc_expand_entries (a rank of a multi-GPU job never reads its own slab's list) */
+                                vc_expand_entries (a rank of a multi-GPU job never reads its own slab's list).
+                                With a communicator attached (vc_comm_init) such a step is a COLLECTIVE call:
+                                it also packs the slab's words and all-gathers the counts, so every rank
+                                must issue the same sequence of them. */
 };
 
 #define VC_MAX_CAMERAS 16

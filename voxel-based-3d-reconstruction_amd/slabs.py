@@ -67,11 +67,13 @@ def measure_chunk_cost(engine, nz, chunk, mode="lut", repeats=5, reduce_max=None
         engine.set_slab(z, min(z + chunk, nz))
         if mode == "lut":
             engine.build_lut()
+        # records kept: with a communicator attached a records=False step is a collective call, and this
+        # loop must not depend on what the other ranks are doing (only the kernel time is read)
         for _ in range(2):
-            engine.carve(mode=mode, records=False, **carve_kwargs)
+            engine.carve(mode=mode, **carve_kwargs)
         engine.timing(reset=True)
         for _ in range(repeats):
-            engine.carve(mode=mode, records=False, **carve_kwargs)
+            engine.carve(mode=mode, **carve_kwargs)
         tm = engine.timing()
         out.append(tm["carve_ms_sum"] / max(1, tm["carve_launches"]))
     floor = 0.6 * min(out)                                  # most of an empty chunk's time is launch + start-up
