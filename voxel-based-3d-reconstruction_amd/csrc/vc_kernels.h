@@ -24,6 +24,10 @@ struct CarveParams {
     const uint32_t *maskbits;   // [C][mwords] of the active frame set
     const int32_t *lut;         // [C][n_pad]
     const uint64_t *bbox;       // [C][n_pad/64] pixel bounding box of each 64-voxel word (u16 u0,v0,u1,v1)
+    const int32_t *lut_tile;    // [C][n_pad] the same table in tile order: word T = 4 x-rows x 16 y of one z-layer
+    const uint64_t *tbox;       // [C][n_pad/64] pixel boxes of the tile words
+    uint32_t tq;                // tile words per row quad = ny / 16
+    uint32_t tile_whole;        // 64 % tq == 0: the 64 tile words of a wave are exactly one y-major group
     const uint32_t *blockgrid;  // [2][C][gh][gws] per 2^gshift-pixel block: "any pixel foreground", then "every pixel foreground"
     uint32_t gshift, gws, gh;   // block-grid geometry
     uint64_t *words;
@@ -301,7 +305,12 @@ __device__ __forceinline__ uint32_t box_test(const uint32_t *__restrict__ g_any,
 //               others are recorded in the word's `need` mask.  Words with an empty `need` mask are
 //               final (all 64 voxels survive); the rest take the exact per-voxel test, only for the
 //               cameras in their mask.  Exact: the box contains the pixel of every voxel of the word.
-template <int B, bool HIER, bool PAIR>
+// TILE: the 64 voxels of a word are 4 neighbouring x-rows x 16 consecutive y of one z-layer instead of
+// 64 consecutive y.  A compact footprint has a pixel box of ~2 blocks instead of ~5, so the box test
+// decides more words (undecided 7 % -> 3.8 % in the hull's layers at 1024^3, scripts/exp_shapes.py).
+// Needs nx % 4 == 0 and ny % 64 == 0; the table and the boxes are kept in that order too
+// (k_tile_lut), and the wave transposes its 64 result words back to y-major before storing them.
+template <int B, bool HIER, bool PAIR, bool TILE = false>
 __device__ __forceinline__ void lut_refine_body(const CarveParams &p, uint32_t vblock, uint32_t nblocks, uint32_t *s_grid)
 {
     const uint32_t gridwords = p.C * p.gh * p.gws;
@@ -331,7 +340,7 @@ __device__ __forceinline__ void lut_refine_body(const CarveParams &p, uint32_t v
                 uint64_t bb[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    bb[k] = (q0 + k < p.C) ? p.bbox[(size_t)p.order[q0 + k] * nwords + gw + lane] : 0ull;
+                    bb[k] = (q0 + k < p.C) ? (TILE ? p.tbox : p.bbox)[(size_t)p.order[q0 + k] * nwords + gw + lane] : 0ull;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (q0 + k < p.C && cand) {
@@ -343,7 +352,7 @@ __device__ __forceinline__ void lut_refine_body(const CarveParams &p, uint32_t v
                 }
             }
             // a live word starts with every voxel of the slab alive (padding excluded)
-            const uint64_t j0 = (gw + lane) << 6;
+            const uint64_t j0 = (gw + lane) << 6;                 // TILE: n % 64 == 0, a word is whole or padding
             mine = 0;
             if (cand && j0 < p.n) mine = (p.n - j0 >= 64) ? ~0ull : ((1ull << (p.n - j0)) - 1ull);
             if (!cand) need = 0;
@@ -377,8 +386,8 @@ __device__ __forceinline__ void lut_refine_body(const CarveParams &p, uint32_t v
                 if (((ndany >> q) & (PAIR ? 3u : 1u)) == 0) continue;   // decided by the boxes for the whole batch
                 const bool two = PAIR && q + 1 < p.C;
                 const uint32_t c = p.order[q], c2 = p.order[two ? q + 1 : q];
-                const int32_t *__restrict__ L = p.lut + (size_t)c * p.n_pad + gw * 64 + lane;
-                const int32_t *__restrict__ L2 = p.lut + (size_t)c2 * p.n_pad + gw * 64 + lane;
+                const int32_t *__restrict__ L = (TILE ? p.lut_tile : p.lut) + (size_t)c * p.n_pad + gw * 64 + lane;
+                const int32_t *__restrict__ L2 = (TILE ? p.lut_tile : p.lut) + (size_t)c2 * p.n_pad + gw * 64 + lane;
                 const uint32_t *__restrict__ mb = p.maskbits + (size_t)c * p.mwords;
                 const uint32_t *__restrict__ mb2 = p.maskbits + (size_t)c2 * p.mwords;
                 int32_t off[B], off2[B];
@@ -408,6 +417,43 @@ __device__ __forceinline__ void lut_refine_body(const CarveParams &p, uint32_t v
                 }
             }
         }
+        // The words of a group without survivors are NOT written (5 of 6 groups at 1024^3): every reader
+        // looks at groupcnt first (expansion, packing), vc_fetch_occupancy zero-fills them on demand.
+        const bool whole = HIER && (!TILE || p.tile_whole);       // this wave's 64 words are y-major group g
+        if (whole && __ballot(mine != 0) == 0) {
+            if (lane == 0) p.groupcnt[g] = 0;
+            continue;
+        }
+        if (TILE) {
+            // lane (r, k) assembles the y-major word of row r, y chunk k from tile words 4k .. 4k+3 (16 bits each)
+            const uint32_t r = lane >> 4, k = lane & 15u;
+            uint64_t out = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int src = (int)(4 * k + q);
+                const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)mine, src);
+                const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(mine >> 32), src);
+                const uint64_t m = ((uint64_t)hi << 32) | lo;
+                out |= ((m >> (16 * r)) & 0xffffull) << (16 * q);
+            }
+            const uint64_t T = gw + 4 * k;                        // first of the four tile words
+            if (T < (p.n >> 6)) {
+                const uint32_t quad = (uint32_t)(T / p.tq), ty = (uint32_t)(T - (uint64_t)quad * p.tq);
+                const uint32_t qpl = p.nx >> 2;                   // row quads per layer
+                const uint32_t izl = quad / qpl, qx = quad - izl * qpl;
+                const uint64_t lw = (((uint64_t)izl * p.nx + qx * 4 + r) * p.ny + (uint64_t)ty * 16) >> 6;
+                p.words[lw] = out;
+                const uint32_t pc = (uint32_t)__popcll(out);
+                if (!p.tile_whole && pc) atomicAdd(&p.groupcnt[lw >> 6], pc);      // groupcnt zeroed before the launch
+            }
+            if (p.tile_whole) {
+                uint32_t cnt = (uint32_t)__popcll(mine);
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
+                if (lane == 0) p.groupcnt[g] = cnt;
+            }
+            continue;
+        }
         p.words[gw + lane] = mine;
         uint32_t cnt = (uint32_t)__popcll(mine);
 #pragma unroll
@@ -416,11 +462,11 @@ __device__ __forceinline__ void lut_refine_body(const CarveParams &p, uint32_t v
     }
 }
 
-template <int B, bool HIER, bool PAIR>
+template <int B, bool HIER, bool PAIR, bool TILE = false>
 __global__ __launch_bounds__(kBlock) void k_lut_refine(const CarveParams p)
 {
     extern __shared__ uint32_t s_grid[];                          // HIER: [2][C][gh][gws]
-    lut_refine_body<B, HIER, PAIR>(p, blockIdx.x, gridDim.x, s_grid);
+    lut_refine_body<B, HIER, PAIR, TILE>(p, blockIdx.x, gridDim.x, s_grid);
 }
 
 // ---------------------------------------------------------------- fused carve
@@ -620,6 +666,10 @@ __global__ __launch_bounds__(kBlock) void k_carve_fused_hier(const CarveParams p
             const uint64_t nb = __ballot(alive);
             if (lane == l) mine = nb;
         }
+        if (__ballot(mine != 0) == 0) {                           // dead group: count only (see lut_refine_body)
+            if (lane == 0) p.groupcnt[g] = 0;
+            continue;
+        }
         p.words[gw + lane] = mine;
         uint32_t cnt = (uint32_t)__popcll(mine);
 #pragma unroll
@@ -672,6 +722,39 @@ __global__ __launch_bounds__(kBlock) void k_build_lut(const CarveParams p, int32
         const bool inside = __ballot(off >= 0) == ~0ull;          // every voxel of the word lands in the image
         if (bbox && (threadIdx.x & 63u) == 0)
             bbox[(size_t)c * nwords + (j >> 6)] =
+                (u0 == 0xffffu) ? kEmptyBox
+                                : ((uint64_t)u0 | ((uint64_t)v0 << 16) | ((uint64_t)u1 << 32) | ((uint64_t)v1 << 48) |
+                                   (inside ? kBoxAllInside : 0ull));
+    }
+}
+
+// The table and the word boxes once more in tile order (see lut_refine_body<TILE>): element e of tile
+// word T is row r = e / 16 of its row quad, y = 16 * ty + e % 16.  A permutation of the linear table.
+__global__ __launch_bounds__(kBlock) void k_tile_lut(const CarveParams p, const int32_t *__restrict__ lut,
+                                                     int32_t *__restrict__ lut_tile, uint64_t *__restrict__ tbox)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;      // grid covers n_pad exactly
+    const uint64_t T = t >> 6;
+    const uint32_t e = (uint32_t)t & 63u, r = e >> 4, yy = e & 15u;
+    const bool valid = t < p.n;
+    uint64_t j = 0;
+    if (valid) {
+        const uint32_t quad = (uint32_t)(T / p.tq), ty = (uint32_t)(T - (uint64_t)quad * p.tq);
+        const uint32_t qpl = p.nx >> 2;
+        const uint32_t izl = quad / qpl, qx = quad - izl * qpl;
+        j = ((uint64_t)izl * p.nx + qx * 4 + r) * p.ny + (uint64_t)ty * 16 + yy;
+    }
+    const uint64_t nwords = p.n_pad >> 6;
+    for (uint32_t c = 0; c < p.C; ++c) {
+        const int32_t off = valid ? lut[(size_t)c * p.n_pad + j] : -1;
+        lut_tile[(size_t)c * p.n_pad + t] = off;
+        const uint32_t pv = off >= 0 ? (uint32_t)off / p.W : 0u;
+        const uint32_t pu = off >= 0 ? (uint32_t)off - pv * p.W : 0u;
+        const uint32_t u0 = wave_min_u32(off >= 0 ? pu : 0xffffu), u1 = wave_max_u32(pu);
+        const uint32_t v0 = wave_min_u32(off >= 0 ? pv : 0xffffu), v1 = wave_max_u32(pv);
+        const bool inside = __ballot(off >= 0) == ~0ull;
+        if (e == 0)
+            tbox[(size_t)c * nwords + T] =
                 (u0 == 0xffffu) ? kEmptyBox
                                 : ((uint64_t)u0 | ((uint64_t)v0 << 16) | ((uint64_t)u1 << 32) | ((uint64_t)v1 << 48) |
                                    (inside ? kBoxAllInside : 0ull));
@@ -741,15 +824,31 @@ __global__ __launch_bounds__(kBlock) void k_count_groups(const uint64_t *__restr
     if (lane == 0) groupcnt[g] = cnt;
 }
 
+// Zero-fills the words of the groups the hierarchical kernels left unwritten (no survivors).
+__global__ __launch_bounds__(kBlock) void k_zero_dead_groups(uint64_t *__restrict__ words, uint64_t nwords, uint32_t ngroups,
+                                                             const uint32_t *__restrict__ survcnt)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t g = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    if (g >= ngroups || survcnt[g] != 0) return;
+    const uint64_t w = (uint64_t)g * kGroupWords + lane;
+    if (w < nwords) words[w] = 0ull;
+}
+
 // ---- compact exchange form of a carve result (multi-GPU): the non-zero words of the slab as
 // {bits, global index of bit 0} pairs, ascending.  A slab's hull fills ~1 word in 25, so the pairs
 // are ~30x smaller than the survivor records they expand to.
 __global__ __launch_bounds__(kBlock) void k_count_nz(const uint64_t *__restrict__ words, uint64_t nwords,
-                                                     uint32_t ngroups, uint32_t *__restrict__ groupcnt)
+                                                     uint32_t ngroups, const uint32_t *__restrict__ survcnt,
+                                                     uint32_t *__restrict__ groupcnt)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t g = (blockIdx.x * kBlock + threadIdx.x) >> 6;
     if (g >= ngroups) return;
+    if (survcnt[g] == 0) {                                              // its words may be unwritten
+        if (lane == 0) groupcnt[g] = 0;
+        return;
+    }
     const uint64_t w = (uint64_t)g * kGroupWords + lane;
     const uint64_t nz = __ballot(w < nwords && words[w] != 0ull);
     if (lane == 0) groupcnt[g] = (uint32_t)__popcll(nz);
@@ -757,7 +856,8 @@ __global__ __launch_bounds__(kBlock) void k_count_nz(const uint64_t *__restrict_
 
 // mine[0] = entry count, mine[1] = survivor count of this rank (what the counts all-gather sends).
 __global__ __launch_bounds__(kBlock) void k_pack_entries(const uint64_t *__restrict__ words, uint64_t nwords,
-                                                         uint32_t ngroups, const uint32_t *__restrict__ groupoff,
+                                                         uint32_t ngroups, const uint32_t *__restrict__ survcnt,
+                                                         const uint32_t *__restrict__ groupoff,
                                                          const uint64_t *__restrict__ blockoff, uint32_t nscan,
                                                          uint64_t i0, const uint64_t *__restrict__ survivors,
                                                          uint64_t *__restrict__ entries, uint64_t *__restrict__ mine)
@@ -766,6 +866,7 @@ __global__ __launch_bounds__(kBlock) void k_pack_entries(const uint64_t *__restr
     const uint32_t g = (blockIdx.x * kBlock + threadIdx.x) >> 6;
     if (blockIdx.x == 0 && threadIdx.x == 0) { mine[0] = blockoff[nscan]; mine[1] = *survivors; }
     if (g >= ngroups) return;
+    if (survcnt[g] == 0) return;
     const uint64_t w = (uint64_t)g * kGroupWords + lane;
     const uint64_t bits = (w < nwords) ? words[w] : 0ull;
     const uint64_t nz = __ballot(bits != 0ull);

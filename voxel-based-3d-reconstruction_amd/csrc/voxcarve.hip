@@ -128,6 +128,7 @@ struct StepBuf {
     EmitParams emit;                         // kept for a re-run after a records regrow
     bool allseen = false, want_vm = false, has_first = false;
     bool no_records = false;                 // VC_FLAG_NO_RECORDS: occupancy words + count only
+    bool sparse_words = false;               // words of groups with groupcnt == 0 were left unwritten
     // compact exchange form of this step: non-zero words as {bits, global index of bit 0} pairs
     DevBuf<uint64_t> ent, mine, counts;      // pairs | {entries, survivors} of this rank | of all ranks
     uint64_t *h_counts = nullptr;            // pinned, 2 per rank
@@ -164,6 +165,10 @@ struct vc_ctx {
 
     DevBuf<int32_t> d_lut;
     DevBuf<uint64_t> d_bbox;         // [C][n_pad/64] per-word pixel boxes (built with the LUT)
+    DevBuf<int32_t> d_lut_tile;      // the table in tile order (words of 4 x-rows x 16 y), when the grid allows
+    DevBuf<uint64_t> d_tbox;         // pixel boxes of the tile words
+    bool tile_valid = false;
+    int lut_tile = 1;                // hierarchical LUT kernel on tile words (needs nx % 4 == 0, ny % 64 == 0)
     uint32_t gshift = 2, gws = 1, gh = 1;   // block grid geometry for H x W
     bool lut_valid = false;
     DevBuf<uint32_t> d_est;          // per-camera pass counts of k_estimate
@@ -279,6 +284,8 @@ void fill_params(const vc_ctx *ctx, CarveParams &p)
     p.C = ctx->C; p.H = ctx->H; p.W = ctx->W; p.mwords = ctx->mwords;
     memcpy(p.cam, ctx->cams, sizeof(CamDev) * ctx->C);
     p.bbox = ctx->d_bbox.ptr;
+    p.lut_tile = ctx->d_lut_tile.ptr; p.tbox = ctx->d_tbox.ptr; p.tq = ctx->ny / 16;
+    p.tile_whole = (p.tq != 0 && 64 % p.tq == 0) ? 1u : 0u;
     p.gshift = ctx->gshift; p.gws = ctx->gws; p.gh = ctx->gh;
 }
 
@@ -368,10 +375,11 @@ int enqueue_pack(vc_ctx *ctx, StepBuf &cur)
     VC_TRY(ensure_exchange_scratch(ctx, ngroups));
     VC_TRY(ensure(ctx, cur.ent, (size_t)(2 * nwords)));          // worst case: every word non-zero (n / 4 bytes)
     const dim3 grid((ngroups + 3) / 4), block(kBlock);
-    hipLaunchKernelGGL(k_count_nz, grid, block, 0, ctx->stream, cur.words.ptr, nwords, ngroups, ctx->d_xcnt.ptr);
+    hipLaunchKernelGGL(k_count_nz, grid, block, 0, ctx->stream, cur.words.ptr, nwords, ngroups, cur.groupcnt.ptr,
+                       ctx->d_xcnt.ptr);
     VC_HIP(ctx, hipGetLastError());
     VC_TRY(scan_counts(ctx, ctx->d_xcnt.ptr, ngroups, ctx->d_xoff.ptr, ctx->d_xbsum.ptr, ctx->d_xboff.ptr, ctx->h_xtotal));
-    hipLaunchKernelGGL(k_pack_entries, grid, block, 0, ctx->stream, cur.words.ptr, nwords, ngroups, ctx->d_xoff.ptr,
+    hipLaunchKernelGGL(k_pack_entries, grid, block, 0, ctx->stream, cur.words.ptr, nwords, ngroups, cur.groupcnt.ptr, ctx->d_xoff.ptr,
                        ctx->d_xboff.ptr, nscan, ctx->i0(), cur.blockoff.ptr + nscan, cur.ent.ptr, cur.mine.ptr);
     VC_HIP(ctx, hipGetLastError());
     return VC_OK;
@@ -537,7 +545,7 @@ int vc_destroy(vc_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
     for (Slot &s : ctx->slots) { release(s.bits); release(s.frames); release(s.grid); }
-    release(ctx->d_axes); release(ctx->d_stage); release(ctx->d_morph); release(ctx->d_lut); release(ctx->d_bbox);
+    release(ctx->d_axes); release(ctx->d_stage); release(ctx->d_morph); release(ctx->d_lut); release(ctx->d_bbox); release(ctx->d_lut_tile); release(ctx->d_tbox);
     for (StepBuf &b : ctx->sb) {
         release(b.words); release(b.groupcnt); release(b.groupoff); release(b.blocksum); release(b.blockoff); release(b.records);
         release(b.ent); release(b.mine); release(b.counts);
@@ -764,6 +772,16 @@ int vc_build_lut(vc_ctx *ctx)
         VC_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
         hipLaunchKernelGGL(k_build_lut, dim3(grid_for(n_pad)), dim3(kBlock), 0, ctx->stream, p, ctx->d_lut.ptr, ctx->d_bbox.ptr);
         VC_HIP(ctx, hipGetLastError());
+        ctx->tile_valid = false;
+        if (ctx->lut_tile && ctx->nx % 4 == 0 && ctx->ny % 64 == 0) {
+            VC_TRY(ensure(ctx, ctx->d_lut_tile, (size_t)n_pad * ctx->C));
+            VC_TRY(ensure(ctx, ctx->d_tbox, (size_t)(n_pad / 64) * ctx->C));
+            fill_params(ctx, p);
+            hipLaunchKernelGGL(k_tile_lut, dim3(grid_for(n_pad)), dim3(kBlock), 0, ctx->stream, p, ctx->d_lut.ptr,
+                               ctx->d_lut_tile.ptr, ctx->d_tbox.ptr);
+            VC_HIP(ctx, hipGetLastError());
+            ctx->tile_valid = true;
+        }
         VC_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
         VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
         VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.lut_ms, ctx->ev[0], ctx->ev[1]));
@@ -821,6 +839,7 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     sb.n = n; sb.survivors = 0; sb.want_vm = want_vm; sb.has_first = false;
     sb.allseen = min_views >= ctx->C;
     sb.no_records = (flags & VC_FLAG_NO_RECORDS) != 0;
+    sb.sparse_words = false;
     sb.mode = mode; sb.color_cam = color_cam; sb.slot = slot;
     // a rank of a communicator packs and exchanges the counts right behind the carve, so that
     // vc_allgather finds them on the host and only has the payload and the expansion left
@@ -896,7 +915,15 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
             const uint64_t rwant = (groups + 3) / 4;
             const uint64_t rmax = 256ull * (uint64_t)ctx->hier_blocks_per_cu;
             const dim3 rgrid((uint32_t)(rwant < rmax ? rwant : rmax));
-            if (ctx->refine_pair) hipLaunchKernelGGL((k_lut_refine<8, true, true>), rgrid, block, lds, ctx->stream, p);
+            sb.sparse_words = true;
+            if (ctx->lut_tile && ctx->tile_valid) {
+                if (!p.tile_whole) {             // waves and groups do not coincide: counts by atomics, every word stored
+                    VC_HIP(ctx, hipMemsetAsync(sb.groupcnt.ptr, 0, sizeof(uint32_t) * ngroups, ctx->stream));
+                    sb.sparse_words = false;
+                }
+                hipLaunchKernelGGL((k_lut_refine<8, true, true, true>), rgrid, block, lds, ctx->stream, p);
+            }
+            else if (ctx->refine_pair) hipLaunchKernelGGL((k_lut_refine<8, true, true>), rgrid, block, lds, ctx->stream, p);
             else if (ctx->refine_b == 8) hipLaunchKernelGGL((k_lut_refine<8, true, false>), rgrid, block, lds, ctx->stream, p);
             else hipLaunchKernelGGL((k_lut_refine<16, true, false>), rgrid, block, lds, ctx->stream, p);
             VC_HIP(ctx, hipEventRecord(sb.e_first, ctx->stream));
@@ -931,6 +958,7 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
             const uint64_t rmax = 256ull * (uint64_t)ctx->hier_blocks_per_cu;
             const dim3 rgrid((uint32_t)(rwant < rmax ? rwant : rmax));
             hipLaunchKernelGGL(k_carve_fused_hier, rgrid, block, lds, ctx->stream, p);
+            sb.sparse_words = true;
         }
         else if (ctx->ny % 64 == 0) hipLaunchKernelGGL((k_carve_fused<kSub, true>), grid, block, 0, ctx->stream, p);
         else hipLaunchKernelGGL((k_carve_fused<kSub, false>), grid, block, 0, ctx->stream, p);
@@ -1115,7 +1143,16 @@ int vc_fetch_occupancy(vc_ctx *ctx, uint8_t *bits)
     if (!ctx->carved) return fail(ctx, VC_ERR_ARG, "no carve result to fetch");
     VC_HIP(ctx, hipSetDevice(ctx->device));
     const uint64_t nwords = (ctx->n_voxels() + 63) / 64;
-    if (nwords) VC_HIP(ctx, hipMemcpy(bits, ctx->sb[ctx->cur].words.ptr, nwords * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    StepBuf &cur = ctx->sb[ctx->cur];
+    if (nwords && cur.sparse_words) {            // the hierarchical kernels skip the words of groups without survivors
+        const uint32_t ngroups = (uint32_t)((nwords + kGroupWords - 1) / kGroupWords);
+        hipLaunchKernelGGL(k_zero_dead_groups, dim3((ngroups + 3) / 4), dim3(kBlock), 0, ctx->stream, cur.words.ptr, nwords,
+                           ngroups, cur.groupcnt.ptr);
+        VC_HIP(ctx, hipGetLastError());
+        VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        cur.sparse_words = false;
+    }
+    if (nwords) VC_HIP(ctx, hipMemcpy(bits, cur.words.ptr, nwords * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return VC_OK;
 }
 
@@ -1128,6 +1165,7 @@ int vc_set_option(vc_ctx *ctx, const char *name, int value)
     else if (k == "lut_hier") ctx->lut_hier = value != 0;
     else if (k == "fused_hier") ctx->fused_hier = value != 0;
     else if (k == "emit_lanes") ctx->emit_lanes = value != 0;
+    else if (k == "lut_tile") ctx->lut_tile = value != 0;
     else if (k == "gather_compact") ctx->gather_compact = value != 0;
     else if (k == "gather_sync") ctx->gather_sync = value != 0;
     else if (k == "refine_pair") ctx->refine_pair = value != 0;
