@@ -141,8 +141,10 @@ def test_random_scenes_ragged_shapes(eng, seed):
 
 @pytest.mark.parametrize("seed", range(4))
 def test_every_kernel_family_agrees_with_oracle(eng, seed):
-    """The same scene through each carve implementation: hierarchical LUT (default), streaming LUT
-    (k_lut_first + k_lut_refine), chunked fused, and the one-thread-per-voxel kernels."""
+    """The same scene through each carve implementation: hierarchical LUT on tile words (default where nx % 4 == 0 and
+    ny % 64 == 0; grid 2 is the case whose waves do not coincide with y-major groups) and on y-line words, streaming LUT
+    (k_lut_first + k_lut_refine), chunked fused, and the one-thread-per-voxel kernels.  The dense occupancy too: the
+    hierarchical kernels leave the words of dead groups unwritten and vc_fetch_occupancy has to fill them in."""
     from oracle import carve_c
     cams3, masks3, frames3 = fx.random_scene(100 + seed, C=4, H=60 + 7 * seed, W=80, fg=0.55)
     grid = [(16, 128, 24), (40, 64, 9), (8, 192, 33), (5, 70, 19)][seed]        # last: ny % 64 != 0
@@ -154,7 +156,7 @@ def test_every_kernel_family_agrees_with_oracle(eng, seed):
     eng.upload_frame(2, frames3[2])
     eng.build_lut()
     try:
-        for opts in ({"lut_hier": 1}, {"lut_hier": 0}, {"lut_hier": 0, "first_kv": 4}, {"lut_hier": 1, "refine_b": 16, "refine_pair": 0},
+        for opts in ({"lut_hier": 1}, {"lut_tile": 0}, {"lut_hier": 0}, {"lut_hier": 0, "first_kv": 4}, {"lut_hier": 1, "refine_b": 16, "refine_pair": 0},
                      {"reorder": 0}, {"fused_hier": 0}, {"refine_pair": 0}, {"emit_lanes": 0}, {"force_generic": 1}):
             for k, v in opts.items():
                 eng.set_option(k, v)
@@ -162,10 +164,14 @@ def test_every_kernel_family_agrees_with_oracle(eng, seed):
                 assert eng.carve(mode=mode, color_cam=2) == want["count"], (opts, mode)
                 idx, rgb, seen = eng.fetch()
                 assert np.array_equal(idx, want["idx"]) and np.array_equal(rgb[:, ::-1], want["bgr"]) and seen.all(), (opts, mode)
+                occ = np.zeros(grid[0] * grid[1] * grid[2], bool)
+                occ[want["idx"]] = True
+                assert np.array_equal(eng.fetch_occupancy(), occ), (opts, mode)
+                assert int(np.bitwise_count(eng.pack_entries()[:, 0]).sum()) == want["count"], (opts, mode)
             for k in opts:
-                eng.set_option(k, {"lut_hier": 1, "first_kv": 1, "refine_b": 8, "reorder": 1, "fused_hier": 1, "refine_pair": 1, "emit_lanes": 1, "force_generic": 0}[k])
+                eng.set_option(k, {"lut_hier": 1, "lut_tile": 1, "first_kv": 1, "refine_b": 8, "reorder": 1, "fused_hier": 1, "refine_pair": 1, "emit_lanes": 1, "force_generic": 0}[k])
     finally:
-        for k, v in {"lut_hier": 1, "first_kv": 1, "refine_b": 8, "reorder": 1, "fused_hier": 1, "refine_pair": 1, "emit_lanes": 1, "force_generic": 0}.items():
+        for k, v in {"lut_hier": 1, "lut_tile": 1, "first_kv": 1, "refine_b": 8, "reorder": 1, "fused_hier": 1, "refine_pair": 1, "emit_lanes": 1, "force_generic": 0}.items():
             eng.set_option(k, v)
     with pytest.raises(Exception):
         eng.set_option("no_such_option", 1)
