@@ -298,6 +298,40 @@ __device__ __forceinline__ uint32_t box_test(const uint32_t *__restrict__ g_any,
     return (miss == 0 && (bb & kBoxAllInside)) ? 2u : 1u;
 }
 
+// Result of a wave that worked on tile words (lane = tile word gw + lane, 4 x-rows x 16 y each): lane (r, k)
+// assembles the y-major word of row r, y chunk k from tile words 4k .. 4k+3 (16 bits each) and stores it.
+// tile_whole: the wave's words are exactly y-major group g, its count is stored; otherwise the counts
+// are accumulated with atomics into a zeroed groupcnt.
+__device__ __forceinline__ void tile_store(const CarveParams &p, uint32_t g, uint64_t gw, uint32_t lane, uint64_t mine)
+{
+    const uint32_t r = lane >> 4, k = lane & 15u;
+    uint64_t out = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int src = (int)(4 * k + q);
+        const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)mine, src);
+        const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(mine >> 32), src);
+        const uint64_t m = ((uint64_t)hi << 32) | lo;
+        out |= ((m >> (16 * r)) & 0xffffull) << (16 * q);
+    }
+    const uint64_t T = gw + 4 * k;                                // first of the four tile words
+    if (T < (p.n >> 6)) {
+        const uint32_t quad = (uint32_t)(T / p.tq), ty = (uint32_t)(T - (uint64_t)quad * p.tq);
+        const uint32_t qpl = p.nx >> 2;                           // row quads per layer
+        const uint32_t izl = quad / qpl, qx = quad - izl * qpl;
+        const uint64_t lw = (((uint64_t)izl * p.nx + qx * 4 + r) * p.ny + (uint64_t)ty * 16) >> 6;
+        p.words[lw] = out;
+        const uint32_t pc = (uint32_t)__popcll(out);
+        if (!p.tile_whole && pc) atomicAdd(&p.groupcnt[lw >> 6], pc);
+    }
+    if (p.tile_whole) {
+        uint32_t cnt = (uint32_t)__popcll(mine);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
+        if (lane == 0) p.groupcnt[g] = cnt;
+    }
+}
+
 // HIER = false: refines the alive words k_lut_first left, cameras order[1..].
 // HIER = true : no first pass at all.  Coarse pass, lane = word: each camera's pixel box of the word
 //               against that camera's block grids (LDS).  Any camera with no foreground block in the
@@ -425,33 +459,7 @@ __device__ __forceinline__ void lut_refine_body(const CarveParams &p, uint32_t v
             continue;
         }
         if (TILE) {
-            // lane (r, k) assembles the y-major word of row r, y chunk k from tile words 4k .. 4k+3 (16 bits each)
-            const uint32_t r = lane >> 4, k = lane & 15u;
-            uint64_t out = 0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int src = (int)(4 * k + q);
-                const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)mine, src);
-                const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(mine >> 32), src);
-                const uint64_t m = ((uint64_t)hi << 32) | lo;
-                out |= ((m >> (16 * r)) & 0xffffull) << (16 * q);
-            }
-            const uint64_t T = gw + 4 * k;                        // first of the four tile words
-            if (T < (p.n >> 6)) {
-                const uint32_t quad = (uint32_t)(T / p.tq), ty = (uint32_t)(T - (uint64_t)quad * p.tq);
-                const uint32_t qpl = p.nx >> 2;                   // row quads per layer
-                const uint32_t izl = quad / qpl, qx = quad - izl * qpl;
-                const uint64_t lw = (((uint64_t)izl * p.nx + qx * 4 + r) * p.ny + (uint64_t)ty * 16) >> 6;
-                p.words[lw] = out;
-                const uint32_t pc = (uint32_t)__popcll(out);
-                if (!p.tile_whole && pc) atomicAdd(&p.groupcnt[lw >> 6], pc);      // groupcnt zeroed before the launch
-            }
-            if (p.tile_whole) {
-                uint32_t cnt = (uint32_t)__popcll(mine);
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
-                if (lane == 0) p.groupcnt[g] = cnt;
-            }
+            tile_store(p, g, gw, lane, mine);
             continue;
         }
         p.words[gw + lane] = mine;
@@ -564,16 +572,18 @@ __device__ __forceinline__ Iv iv_sqr(Iv a)
     return {fmin(l, h), fmax(l, h)};
 }
 
-// Pixel box of the segment {(X, y, Z): y in [ya, yb]} for camera c, packed as bbox words are;
-// kEmptyBox when no voxel of it can be inside the image; ~1ull ("maybe") when it cannot be bounded.
+// Pixel box of the voxel set {(x, y, Z): x in [xa, xb], y in [ya, yb]} for camera c (a y-line word has
+// xa == xb), packed as bbox words are; kEmptyBox when no voxel of it can be inside the image; ~1ull
+// ("maybe") when it cannot be bounded.
 constexpr uint64_t kMaybeBox = ~1ull;
-__device__ __forceinline__ uint64_t segment_box(const CamDev &c, double X, double ya, double yb, double Z,
+__device__ __forceinline__ uint64_t segment_box(const CamDev &c, double xa, double xb, double ya, double yb, double Z,
                                                 uint32_t H, uint32_t W)
 {
+    const Iv X = {fmin(xa, xb), fmax(xa, xb)};
     const Iv Y = {fmin(ya, yb), fmax(ya, yb)};
-    const Iv x = iv_addc(iv_scale(Y, c.r[1]), c.r[0] * X + c.r[2] * Z + c.t[0]);
-    const Iv y = iv_addc(iv_scale(Y, c.r[4]), c.r[3] * X + c.r[5] * Z + c.t[1]);
-    const Iv z = iv_addc(iv_scale(Y, c.r[7]), c.r[6] * X + c.r[8] * Z + c.t[2]);
+    const Iv x = iv_addc(iv_add(iv_scale(X, c.r[0]), iv_scale(Y, c.r[1])), c.r[2] * Z + c.t[0]);
+    const Iv y = iv_addc(iv_add(iv_scale(X, c.r[3]), iv_scale(Y, c.r[4])), c.r[5] * Z + c.t[1]);
+    const Iv z = iv_addc(iv_add(iv_scale(X, c.r[6]), iv_scale(Y, c.r[7])), c.r[8] * Z + c.t[2]);
     // keep a margin around z = 0: there the projection takes the `z ? 1/z : 1` branch or blows up
     const double zmag = fmax(fabs(z.lo), fabs(z.hi));
     if (!(z.lo > 1e-6 * zmag || z.hi < -1e-6 * zmag) || zmag == 0.0) return kMaybeBox;
@@ -602,6 +612,9 @@ __device__ __forceinline__ uint64_t segment_box(const CamDev &c, double X, doubl
     return (uint64_t)u0 | ((uint64_t)v0 << 16) | ((uint64_t)u1 << 32) | ((uint64_t)v1 << 48) | (inside ? kBoxAllInside : 0ull);
 }
 
+// TILE: words of 4 x-rows x 16 y (see lut_refine_body); the interval of a compact word is tighter in
+// both image directions, and the result words go back to y-major through tile_store.
+template <bool TILE>
 __global__ __launch_bounds__(kBlock) void k_carve_fused_hier(const CarveParams p)
 {
     extern __shared__ uint32_t s_grid[];                          // [2][C][gh][gws]
@@ -621,15 +634,22 @@ __global__ __launch_bounds__(kBlock) void k_carve_fused_hier(const CarveParams p
         // ---- coarse: lane = word
         const uint64_t j0 = (gw + lane) << 6;
         bool cand = j0 < p.n;                                     // n % 64 == 0 here: whole words only
-        uint32_t ix = 0, iy = 0, izl = 0;
-        if (cand) decompose((uint32_t)j0, p.nx, p.ny, ix, iy, izl);
-        const double X = p.xs[ix], Z = p.zs[p.z0 + izl];
-        const double ya = p.ys[iy], yb = p.ys[iy + 63 < p.ny ? iy + 63 : p.ny - 1];
+        uint32_t ix = 0, iy = 0, izl = 0;                         // first voxel of the word
+        if (cand && TILE) {
+            const uint32_t quad = (uint32_t)((gw + lane) / p.tq), qpl = p.nx >> 2;
+            iy = ((uint32_t)(gw + lane) - quad * p.tq) * 16;
+            izl = quad / qpl;
+            ix = (quad - izl * qpl) * 4;
+        } else if (cand) decompose((uint32_t)j0, p.nx, p.ny, ix, iy, izl);
+        const double Z = p.zs[p.z0 + izl];
+        const double xa = p.xs[ix], xb = TILE ? p.xs[ix + 3 < p.nx ? ix + 3 : p.nx - 1] : xa;
+        const uint32_t ylast = TILE ? 15u : 63u;
+        const double ya = p.ys[iy], yb = p.ys[iy + ylast < p.ny ? iy + ylast : p.ny - 1];
         uint32_t need = 0;                                       // cameras still to test voxel by voxel
         for (uint32_t q = 0; q < p.C && __ballot(cand) != 0; ++q) {
             const uint32_t c = p.order[q];
             if (cand) {
-                const uint64_t bb = segment_box(p.cam[c], X, ya, yb, Z, p.H, p.W);
+                const uint64_t bb = segment_box(p.cam[c], xa, xb, ya, yb, Z, p.H, p.W);
                 uint32_t r = 1;
                 if (bb != kMaybeBox) {
                     const uint32_t *ga = s_grid + (size_t)c * p.gh * p.gws;
@@ -650,7 +670,8 @@ __global__ __launch_bounds__(kBlock) void k_carve_fused_hier(const CarveParams p
             const uint32_t wix = (uint32_t)__builtin_amdgcn_readlane((int)ix, (int)l);
             const uint32_t wiy = (uint32_t)__builtin_amdgcn_readlane((int)iy, (int)l);
             const uint32_t wiz = (uint32_t)__builtin_amdgcn_readlane((int)izl, (int)l);
-            const double VX = p.xs[wix], VY = p.ys[wiy + lane], VZ = p.zs[p.z0 + wiz];
+            const double VX = p.xs[TILE ? wix + (lane >> 4) : wix], VY = p.ys[TILE ? wiy + (lane & 15u) : wiy + lane];
+            const double VZ = p.zs[p.z0 + wiz];
             bool alive = true;
             for (uint32_t q = 0; q < p.C; ++q) {
                 if (!((nd >> q) & 1u)) continue;                  // decided for the whole word by its box
@@ -666,8 +687,12 @@ __global__ __launch_bounds__(kBlock) void k_carve_fused_hier(const CarveParams p
             const uint64_t nb = __ballot(alive);
             if (lane == l) mine = nb;
         }
-        if (__ballot(mine != 0) == 0) {                           // dead group: count only (see lut_refine_body)
+        if ((!TILE || p.tile_whole) && __ballot(mine != 0) == 0) {   // dead group: count only (see lut_refine_body)
             if (lane == 0) p.groupcnt[g] = 0;
+            continue;
+        }
+        if (TILE) {
+            tile_store(p, g, gw, lane, mine);
             continue;
         }
         p.words[gw + lane] = mine;

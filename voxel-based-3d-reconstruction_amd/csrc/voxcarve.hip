@@ -169,6 +169,7 @@ struct vc_ctx {
     DevBuf<uint64_t> d_tbox;         // pixel boxes of the tile words
     bool tile_valid = false;
     int lut_tile = 1;                // hierarchical LUT kernel on tile words (needs nx % 4 == 0, ny % 64 == 0)
+    int fused_tile = 1;              // the same word shape for the hierarchical table-free kernel
     uint32_t gshift = 2, gws = 1, gh = 1;   // block grid geometry for H x W
     bool lut_valid = false;
     DevBuf<uint32_t> d_est;          // per-camera pass counts of k_estimate
@@ -957,8 +958,15 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
             const uint64_t rwant = (groups + 3) / 4;
             const uint64_t rmax = 256ull * (uint64_t)ctx->hier_blocks_per_cu;
             const dim3 rgrid((uint32_t)(rwant < rmax ? rwant : rmax));
-            hipLaunchKernelGGL(k_carve_fused_hier, rgrid, block, lds, ctx->stream, p);
             sb.sparse_words = true;
+            if (ctx->fused_tile && ctx->nx % 4 == 0) {            // ny % 64 == 0 here: words of 4 x-rows x 16 y
+                if (!p.tile_whole) {
+                    VC_HIP(ctx, hipMemsetAsync(sb.groupcnt.ptr, 0, sizeof(uint32_t) * ngroups, ctx->stream));
+                    sb.sparse_words = false;
+                }
+                hipLaunchKernelGGL(k_carve_fused_hier<true>, rgrid, block, lds, ctx->stream, p);
+            }
+            else hipLaunchKernelGGL(k_carve_fused_hier<false>, rgrid, block, lds, ctx->stream, p);
         }
         else if (ctx->ny % 64 == 0) hipLaunchKernelGGL((k_carve_fused<kSub, true>), grid, block, 0, ctx->stream, p);
         else hipLaunchKernelGGL((k_carve_fused<kSub, false>), grid, block, 0, ctx->stream, p);
@@ -1166,6 +1174,7 @@ int vc_set_option(vc_ctx *ctx, const char *name, int value)
     else if (k == "fused_hier") ctx->fused_hier = value != 0;
     else if (k == "emit_lanes") ctx->emit_lanes = value != 0;
     else if (k == "lut_tile") ctx->lut_tile = value != 0;
+    else if (k == "fused_tile") ctx->fused_tile = value != 0;
     else if (k == "gather_compact") ctx->gather_compact = value != 0;
     else if (k == "gather_sync") ctx->gather_sync = value != 0;
     else if (k == "refine_pair") ctx->refine_pair = value != 0;
