@@ -304,7 +304,7 @@ def main():
         # measures the skipped work, `traffic` (PMC) is what really crossed the HBM interface.
         alg_bytes = LUT_BYTES_PER_VV * vv_launch
         achieved = alg_bytes / (head["kernel_ms"] * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "k_lut_refine<8,HIER,PAIR> (pixel-box x block-grid reject/accept per word, exact test for undecided words)",
+        roof = {"bound": "hbm", "kernel": "k_lut_refine<8,HIER,PAIR,TILE> (pixel-box x block-grid reject/accept per 64-voxel word, exact test for undecided words)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(head["kernel_ms"], 4),
