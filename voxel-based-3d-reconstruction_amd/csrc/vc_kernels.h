@@ -612,9 +612,83 @@ __device__ __forceinline__ uint64_t segment_box(const CamDev &c, double xa, doub
     return (uint64_t)u0 | ((uint64_t)v0 << 16) | ((uint64_t)u1 << 32) | ((uint64_t)v1 << 48) | (inside ? kBoxAllInside : 0ull);
 }
 
+// The same box with the nonlinear part (division, distortion polynomial, intrinsics) evaluated in
+// float32 intervals: the coarse pass is FP64-VALU bound and this is most of its arithmetic.  The rigid
+// transform stays in float64 (it is where cancellation lives: R.X + t with |t| in the thousands); its
+// three intervals are widened by one float32 ulp when narrowed.  Everything after it only ever
+// multiplies and adds quantities whose magnitudes are tracked (M, Mt below), so the float32 rounding
+// (~1e-7 relative per operation, ~10 operations deep) is bounded by 1e-6 x those magnitudes; the box is
+// widened by 1 px + 1e-5 x them, and a word that cannot be bounded is kept, as before.
+struct Ivf { float lo, hi; };
+__device__ __forceinline__ Ivf ivf_add(Ivf a, Ivf b) { return {a.lo + b.lo, a.hi + b.hi}; }
+__device__ __forceinline__ Ivf ivf_addc(Ivf a, float c) { return {a.lo + c, a.hi + c}; }
+__device__ __forceinline__ Ivf ivf_scale(Ivf a, float k) { return k >= 0 ? Ivf{a.lo * k, a.hi * k} : Ivf{a.hi * k, a.lo * k}; }
+__device__ __forceinline__ Ivf ivf_mul(Ivf a, Ivf b)
+{
+    const float p0 = a.lo * b.lo, p1 = a.lo * b.hi, p2 = a.hi * b.lo, p3 = a.hi * b.hi;
+    return {fminf(fminf(p0, p1), fminf(p2, p3)), fmaxf(fmaxf(p0, p1), fmaxf(p2, p3))};
+}
+__device__ __forceinline__ Ivf ivf_sqr(Ivf a)
+{
+    const float l = a.lo * a.lo, h = a.hi * a.hi;
+    if (a.lo <= 0.0f && a.hi >= 0.0f) return {0.0f, fmaxf(l, h)};
+    return {fminf(l, h), fmaxf(l, h)};
+}
+__device__ __forceinline__ Ivf ivf_from(Iv a)                      // outward by one float32 ulp
+{
+    const float l = (float)a.lo, h = (float)a.hi;
+    return {l - fabsf(l) * 1.2e-7f, h + fabsf(h) * 1.2e-7f};
+}
+
+__device__ __forceinline__ uint64_t segment_box_f32(const CamDev &c, double xa, double xb, double ya, double yb, double Z,
+                                                    uint32_t H, uint32_t W)
+{
+    const Iv X = {fmin(xa, xb), fmax(xa, xb)};
+    const Iv Y = {fmin(ya, yb), fmax(ya, yb)};
+    const Iv xd64 = iv_addc(iv_add(iv_scale(X, c.r[0]), iv_scale(Y, c.r[1])), c.r[2] * Z + c.t[0]);
+    const Iv yd64 = iv_addc(iv_add(iv_scale(X, c.r[3]), iv_scale(Y, c.r[4])), c.r[5] * Z + c.t[1]);
+    const Iv zd64 = iv_addc(iv_add(iv_scale(X, c.r[6]), iv_scale(Y, c.r[7])), c.r[8] * Z + c.t[2]);
+    const double zmag = fmax(fabs(zd64.lo), fabs(zd64.hi));
+    if (!(zd64.lo > 1e-6 * zmag || zd64.hi < -1e-6 * zmag) || zmag == 0.0) return kMaybeBox;
+    const Ivf x = ivf_from(xd64), y = ivf_from(yd64), z = ivf_from(zd64);
+    const Ivf inv = {1.0f / z.hi, 1.0f / z.lo};
+    const Ivf xn = ivf_mul(x, inv), yn = ivf_mul(y, inv);
+    const Ivf x2 = ivf_sqr(xn), y2 = ivf_sqr(yn);
+    const Ivf r2 = ivf_add(x2, y2);
+    const Ivf r4 = ivf_sqr(r2);
+    const Ivf r6 = ivf_mul(r4, r2);
+    const float k1 = (float)c.k1, k2 = (float)c.k2, k3 = (float)c.k3, p1 = (float)c.p1, p2 = (float)c.p2;
+    const float fx = (float)c.fx, fy = (float)c.fy, cx = (float)c.cx, cy = (float)c.cy;
+    const Ivf cdist = ivf_addc(ivf_add(ivf_add(ivf_scale(r2, k1), ivf_scale(r4, k2)), ivf_scale(r6, k3)), 1.0f);
+    const Ivf a1 = ivf_scale(ivf_mul(xn, yn), 2.0f);
+    const Ivf a2 = ivf_add(r2, ivf_scale(x2, 2.0f));
+    const Ivf a3 = ivf_add(r2, ivf_scale(y2, 2.0f));
+    const Ivf xd = ivf_add(ivf_add(ivf_mul(xn, cdist), ivf_scale(a1, p1)), ivf_scale(a2, p2));
+    const Ivf yd = ivf_add(ivf_add(ivf_mul(yn, cdist), ivf_scale(a3, p1)), ivf_scale(a1, p2));
+    Ivf u = ivf_addc(ivf_scale(xd, fx), cx);
+    Ivf v = ivf_addc(ivf_scale(yd, fy), cy);
+    // magnitudes every rounded quantity was built from (not the possibly cancelled values)
+    const float M = 1.0f + fabsf(k1) * r2.hi + fabsf(k2) * r4.hi + fabsf(k3) * r6.hi;
+    const float Mt = 3.0f * (fabsf(p1) + fabsf(p2)) * r2.hi;
+    const float xm = fmaxf(fabsf(xn.lo), fabsf(xn.hi)), ym = fmaxf(fabsf(yn.lo), fabsf(yn.hi));
+    const float mu = 1.0f + 1e-5f * (fabsf(fx) * (xm * M + Mt) + fabsf(cx));
+    const float mv = 1.0f + 1e-5f * (fabsf(fy) * (ym * M + Mt) + fabsf(cy));
+    if (!(isfinite(u.lo) && isfinite(u.hi) && isfinite(v.lo) && isfinite(v.hi) && isfinite(mu) && isfinite(mv))) return kMaybeBox;
+    u.lo -= mu; u.hi += mu;
+    v.lo -= mv; v.hi += mv;
+    if (u.hi < 0.0f || v.hi < 0.0f || u.lo >= (float)W || v.lo >= (float)H) return kEmptyBox;
+    const uint32_t u0 = u.lo > 0.0f ? (uint32_t)u.lo : 0u, v0 = v.lo > 0.0f ? (uint32_t)v.lo : 0u;
+    const uint32_t u1 = u.hi < (float)(W - 1) ? (uint32_t)u.hi : W - 1, v1 = v.hi < (float)(H - 1) ? (uint32_t)v.hi : H - 1;
+    const bool inside = u.lo >= 0.0f && v.lo >= 0.0f && u.hi < (float)W && v.hi < (float)H;
+    return (uint64_t)u0 | ((uint64_t)v0 << 16) | ((uint64_t)u1 << 32) | ((uint64_t)v1 << 48) | (inside ? kBoxAllInside : 0ull);
+}
+
 // TILE: words of 4 x-rows x 16 y (see lut_refine_body); the interval of a compact word is tighter in
 // both image directions, and the result words go back to y-major through tile_store.
-template <bool TILE>
+// BOX: where a word's pixel box comes from -- 0: float64 intervals, 1: float32 intervals after a float64
+// rigid transform, 2: read from the boxes k_build_lut reduced once from the exact pixels (8 bytes per
+// word and camera, geometry only: they survive every new frame set; no table is built or read).
+template <bool TILE, int BOX>
 __global__ __launch_bounds__(kBlock) void k_carve_fused_hier(const CarveParams p)
 {
     extern __shared__ uint32_t s_grid[];                          // [2][C][gh][gws]
@@ -646,10 +720,29 @@ __global__ __launch_bounds__(kBlock) void k_carve_fused_hier(const CarveParams p
         const uint32_t ylast = TILE ? 15u : 63u;
         const double ya = p.ys[iy], yb = p.ys[iy + ylast < p.ny ? iy + ylast : p.ny - 1];
         uint32_t need = 0;                                       // cameras still to test voxel by voxel
-        for (uint32_t q = 0; q < p.C && __ballot(cand) != 0; ++q) {
+        if (BOX == 2) {
+            const uint64_t nwords = p.n_pad >> 6;
+            for (uint32_t q0 = 0; q0 < p.C && __ballot(cand) != 0; q0 += 4) {      // four cameras' boxes in flight
+                uint64_t bb[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    bb[k] = (q0 + k < p.C) ? (TILE ? p.tbox : p.bbox)[(size_t)p.order[q0 + k] * nwords + gw + lane] : 0ull;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (q0 + k < p.C && cand) {
+                        const uint32_t *ga = s_grid + (size_t)p.order[q0 + k] * p.gh * p.gws;
+                        const uint32_t r = box_test(ga, ga + gridwords, bb[k], p.gshift, p.gws);
+                        cand = r != 0;
+                        if (r == 1) need |= 1u << (q0 + k);
+                    }
+                }
+            }
+        }
+        for (uint32_t q = 0; BOX != 2 && q < p.C && __ballot(cand) != 0; ++q) {
             const uint32_t c = p.order[q];
             if (cand) {
-                const uint64_t bb = segment_box(p.cam[c], xa, xb, ya, yb, Z, p.H, p.W);
+                const uint64_t bb = BOX == 1 ? segment_box_f32(p.cam[c], xa, xb, ya, yb, Z, p.H, p.W)
+                                             : segment_box(p.cam[c], xa, xb, ya, yb, Z, p.H, p.W);
                 uint32_t r = 1;
                 if (bb != kMaybeBox) {
                     const uint32_t *ga = s_grid + (size_t)c * p.gh * p.gws;
@@ -720,6 +813,10 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
     return v;
 }
 
+// TILE: thread t is element t % 64 of tile word t / 64 (4 x-rows x 16 y) instead of linear voxel t, so the
+// boxes (and the table, when one is asked for) come out in tile order.  lut or bbox may be null: the
+// table-free kernel only wants the boxes.
+template <bool TILE>
 __global__ __launch_bounds__(kBlock) void k_build_lut(const CarveParams p, int32_t *__restrict__ lut,
                                                       uint64_t *__restrict__ bbox)
 {
@@ -728,7 +825,14 @@ __global__ __launch_bounds__(kBlock) void k_build_lut(const CarveParams p, int32
     double X = 0, Y = 0, Z = 0;
     if (valid) {
         uint32_t ix, iy, izl;
-        decompose((uint32_t)j, p.nx, p.ny, ix, iy, izl);
+        if (TILE) {
+            const uint64_t T = j >> 6;
+            const uint32_t e = (uint32_t)j & 63u;
+            const uint32_t quad = (uint32_t)(T / p.tq), qpl = p.nx >> 2;
+            iy = ((uint32_t)T - quad * p.tq) * 16 + (e & 15u);
+            izl = quad / qpl;
+            ix = (quad - izl * qpl) * 4 + (e >> 4);
+        } else decompose((uint32_t)j, p.nx, p.ny, ix, iy, izl);
         X = p.xs[ix]; Y = p.ys[iy]; Z = p.zs[p.z0 + izl];
     }
     const uint64_t nwords = p.n_pad >> 6;
@@ -739,7 +843,7 @@ __global__ __launch_bounds__(kBlock) void k_build_lut(const CarveParams p, int32
             project_point(p.cam[c], X, Y, Z, u, v);
             off = pixel_offset(u, v, p.H, p.W);
         }
-        lut[(size_t)c * p.n_pad + j] = off;
+        if (lut) lut[(size_t)c * p.n_pad + j] = off;
         const uint32_t pv = off >= 0 ? (uint32_t)off / p.W : 0u;
         const uint32_t pu = off >= 0 ? (uint32_t)off - pv * p.W : 0u;
         const uint32_t u0 = wave_min_u32(off >= 0 ? pu : 0xffffu), u1 = wave_max_u32(pu);

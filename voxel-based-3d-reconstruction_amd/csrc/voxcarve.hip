@@ -168,8 +168,11 @@ struct vc_ctx {
     DevBuf<int32_t> d_lut_tile;      // the table in tile order (words of 4 x-rows x 16 y), when the grid allows
     DevBuf<uint64_t> d_tbox;         // pixel boxes of the tile words
     bool tile_valid = false;
+    bool bbox_valid = false, tbox_valid = false;   // boxes match the grid, slab and cameras (also built without a table)
     int lut_tile = 1;                // hierarchical LUT kernel on tile words (needs nx % 4 == 0, ny % 64 == 0)
     int fused_tile = 1;              // the same word shape for the hierarchical table-free kernel
+    int fused_f32box = 1;            // its word boxes from float32 intervals after a float64 rigid transform ...
+    int fused_boxes = 1;             // ... or read from boxes reduced once from the exact pixels (no table involved)
     uint32_t gshift = 2, gws = 1, gh = 1;   // block grid geometry for H x W
     bool lut_valid = false;
     DevBuf<uint32_t> d_est;          // per-camera pass counts of k_estimate
@@ -356,6 +359,25 @@ int ensure_exchange_scratch(vc_ctx *ctx, uint32_t ngroups)
     return VC_OK;
 }
 
+// Pixel boxes of the slab's words (tile or y-line order) without a lookup table: the table-free
+// hierarchical kernel reads them instead of bounding each word by interval arithmetic.  Geometry only:
+// built once per grid / slab / camera set (the projection of every voxel, as long as vc_build_lut).
+int ensure_boxes(vc_ctx *ctx, bool tile)
+{
+    if (tile ? ctx->tbox_valid : ctx->bbox_valid) return VC_OK;
+    const uint64_t n = ctx->n_voxels();
+    const uint64_t n_pad = (n + kLutPad - 1) / kLutPad * kLutPad;
+    DevBuf<uint64_t> &buf = tile ? ctx->d_tbox : ctx->d_bbox;
+    VC_TRY(ensure(ctx, buf, (size_t)(n_pad / 64) * ctx->C));
+    CarveParams p;
+    fill_params(ctx, p);
+    if (tile) hipLaunchKernelGGL(k_build_lut<true>, dim3(grid_for(n_pad)), dim3(kBlock), 0, ctx->stream, p, (int32_t *)nullptr, buf.ptr);
+    else hipLaunchKernelGGL(k_build_lut<false>, dim3(grid_for(n_pad)), dim3(kBlock), 0, ctx->stream, p, (int32_t *)nullptr, buf.ptr);
+    VC_HIP(ctx, hipGetLastError());
+    (tile ? ctx->tbox_valid : ctx->bbox_valid) = true;
+    return VC_OK;
+}
+
 // Enqueues the packing of the current result's non-zero words into ctx->d_ent ({bits, base} pairs) and
 // {entries, survivors} into ctx->d_mine.  No host synchronisation; *h_xtotal holds the entry count
 // once the stream has drained.
@@ -410,7 +432,7 @@ int ensure_color_table(vc_ctx *ctx, int cam)
     fill_params(ctx, p);
     p.n = n; p.n_pad = n_pad; p.z0 = 0; p.C = 1;
     p.cam[0] = ctx->cams[cam];
-    hipLaunchKernelGGL(k_build_lut, dim3(grid_for(n_pad)), dim3(kBlock), 0, ctx->stream, p, ctx->d_lut_color.ptr,
+    hipLaunchKernelGGL(k_build_lut<false>, dim3(grid_for(n_pad)), dim3(kBlock), 0, ctx->stream, p, ctx->d_lut_color.ptr,
                        (uint64_t *)nullptr);
     VC_HIP(ctx, hipGetLastError());
     ctx->lut_color_cam = cam;
@@ -600,7 +622,7 @@ int vc_set_grid(vc_ctx *ctx, uint32_t nx, uint32_t ny, uint32_t nz, const double
     VC_HIP(ctx, hipMemcpyAsync(ctx->d_axes.ptr + nx + ny, ctx->zs.data(), sizeof(double) * nz, hipMemcpyHostToDevice, ctx->stream));
     VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->have_grid = true;
-    ctx->lut_valid = false; ctx->carved = false; ctx->gathered = false; ctx->viewmask_valid = false;
+    ctx->lut_valid = false; ctx->bbox_valid = false; ctx->tbox_valid = false; ctx->carved = false; ctx->gathered = false; ctx->viewmask_valid = false;
     ctx->lut_color_cam = -1; ctx->packed = false;
     return VC_OK;
 }
@@ -612,7 +634,7 @@ int vc_set_slab(vc_ctx *ctx, uint32_t z0, uint32_t z1)
     if (!ctx->have_grid) return fail(ctx, VC_ERR_ARG, "vc_set_grid must precede vc_set_slab");
     if (z0 > z1 || z1 > ctx->nz) return fail(ctx, VC_ERR_ARG, "slab [%u,%u) outside [0,%u]", z0, z1, ctx->nz);
     ctx->z0 = z0; ctx->z1 = z1;
-    ctx->lut_valid = false; ctx->carved = false; ctx->gathered = false; ctx->viewmask_valid = false;
+    ctx->lut_valid = false; ctx->bbox_valid = false; ctx->tbox_valid = false; ctx->carved = false; ctx->gathered = false; ctx->viewmask_valid = false;
     ctx->packed = false;
     return VC_OK;
 }
@@ -659,7 +681,7 @@ int vc_set_cameras(vc_ctx *ctx, uint32_t C, const double *K9, const double *dist
         (void)hipSetDevice(ctx->device);
         for (Slot &s : ctx->slots) { release(s.bits); release(s.frames); release(s.grid); s.have_masks = false; s.have_frame.clear(); }
     }
-    ctx->lut_valid = false; ctx->carved = false; ctx->gathered = false; ctx->viewmask_valid = false;
+    ctx->lut_valid = false; ctx->bbox_valid = false; ctx->tbox_valid = false; ctx->carved = false; ctx->gathered = false; ctx->viewmask_valid = false;
     ctx->lut_color_cam = -1; ctx->packed = false;
     return VC_OK;
 }
@@ -771,8 +793,9 @@ int vc_build_lut(vc_ctx *ctx)
         CarveParams p;
         fill_params(ctx, p);
         VC_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-        hipLaunchKernelGGL(k_build_lut, dim3(grid_for(n_pad)), dim3(kBlock), 0, ctx->stream, p, ctx->d_lut.ptr, ctx->d_bbox.ptr);
+        hipLaunchKernelGGL(k_build_lut<false>, dim3(grid_for(n_pad)), dim3(kBlock), 0, ctx->stream, p, ctx->d_lut.ptr, ctx->d_bbox.ptr);
         VC_HIP(ctx, hipGetLastError());
+        ctx->bbox_valid = true;
         ctx->tile_valid = false;
         if (ctx->lut_tile && ctx->nx % 4 == 0 && ctx->ny % 64 == 0) {
             VC_TRY(ensure(ctx, ctx->d_lut_tile, (size_t)n_pad * ctx->C));
@@ -782,6 +805,7 @@ int vc_build_lut(vc_ctx *ctx)
                                ctx->d_lut_tile.ptr, ctx->d_tbox.ptr);
             VC_HIP(ctx, hipGetLastError());
             ctx->tile_valid = true;
+            ctx->tbox_valid = true;
         }
         VC_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
         VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -964,9 +988,21 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
                     VC_HIP(ctx, hipMemsetAsync(sb.groupcnt.ptr, 0, sizeof(uint32_t) * ngroups, ctx->stream));
                     sb.sparse_words = false;
                 }
-                hipLaunchKernelGGL(k_carve_fused_hier<true>, rgrid, block, lds, ctx->stream, p);
+                if (ctx->fused_boxes) {
+                    VC_TRY(ensure_boxes(ctx, true));
+                    p.tbox = ctx->d_tbox.ptr;
+                    hipLaunchKernelGGL((k_carve_fused_hier<true, 2>), rgrid, block, lds, ctx->stream, p);
+                }
+                else if (ctx->fused_f32box) hipLaunchKernelGGL((k_carve_fused_hier<true, 1>), rgrid, block, lds, ctx->stream, p);
+                else hipLaunchKernelGGL((k_carve_fused_hier<true, 0>), rgrid, block, lds, ctx->stream, p);
             }
-            else hipLaunchKernelGGL(k_carve_fused_hier<false>, rgrid, block, lds, ctx->stream, p);
+            else if (ctx->fused_boxes) {
+                VC_TRY(ensure_boxes(ctx, false));
+                p.bbox = ctx->d_bbox.ptr;
+                hipLaunchKernelGGL((k_carve_fused_hier<false, 2>), rgrid, block, lds, ctx->stream, p);
+            }
+            else if (ctx->fused_f32box) hipLaunchKernelGGL((k_carve_fused_hier<false, 1>), rgrid, block, lds, ctx->stream, p);
+            else hipLaunchKernelGGL((k_carve_fused_hier<false, 0>), rgrid, block, lds, ctx->stream, p);
         }
         else if (ctx->ny % 64 == 0) hipLaunchKernelGGL((k_carve_fused<kSub, true>), grid, block, 0, ctx->stream, p);
         else hipLaunchKernelGGL((k_carve_fused<kSub, false>), grid, block, 0, ctx->stream, p);
@@ -1175,6 +1211,8 @@ int vc_set_option(vc_ctx *ctx, const char *name, int value)
     else if (k == "emit_lanes") ctx->emit_lanes = value != 0;
     else if (k == "lut_tile") ctx->lut_tile = value != 0;
     else if (k == "fused_tile") ctx->fused_tile = value != 0;
+    else if (k == "fused_f32box") ctx->fused_f32box = value != 0;
+    else if (k == "fused_boxes") ctx->fused_boxes = value != 0;
     else if (k == "gather_compact") ctx->gather_compact = value != 0;
     else if (k == "gather_sync") ctx->gather_sync = value != 0;
     else if (k == "refine_pair") ctx->refine_pair = value != 0;
