@@ -314,11 +314,12 @@ def main():
         roof = stream_roofline(head)
     else:
         achieved = FLOP_PER_VV * vv_launch / (head["kernel_ms"] * 1e-3) / 1e12
-        roof = {"bound": "valu_f64", "kernel": "k_carve_fused_hier (interval word rejection + in-kernel fp64 projection)", "achieved": round(achieved, 3),
+        roof = {"bound": "valu_f64", "kernel": "k_carve_fused_hier<TILE,2> (word rejection/acceptance from per-word pixel boxes, in-kernel fp64 projection for undecided words)", "achieved": round(achieved, 3),
                 "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F64_VALU_PEAK_TFLOPS, 4),
                 "traffic": None, "avg_launch_ms": round(head["kernel_ms"], 4),
-                "note": "52 f64 flop per voxel-view counted for ALL voxel-views; most 64-voxel words are rejected "
-                        "from an interval bound of their projected segment and never projected voxel by voxel"}
+                "note": "52 f64 flop per voxel-view counted for ALL voxel-views; most 64-voxel words are decided "
+                        "from the pixel box of the word (8 B per word and camera, reduced once per camera set) and never "
+                        "projected voxel by voxel"}
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
     roof_stream = stream_roofline(results["lut_stream"]) if args.mode != "lut_stream" else None
     if os.path.exists(traffic_file):
