@@ -9,10 +9,10 @@ frames = fx.synthetic_frames(4, *masks[0].shape)
 eng = voxcarve.CarveEngine(0)
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 eng.set_grid(G, G, G); eng.set_cameras(cams, *masks[0].shape)
-eng.upload_masks(masks); eng.upload_frame(1, frames[1])
 for opt in sys.argv[2:]:
     k, v = opt.split("=")
     eng.set_option(k, int(v))
+eng.upload_masks(masks); eng.upload_frame(1, frames[1])
 ts = []
 for it in range(12):
     n = eng.carve(mode="fused")

@@ -26,6 +26,13 @@ for m in masks:
 def sat(a):
     s = np.zeros((a.shape[0] + 1, a.shape[1] + 1), np.int64); s[1:, 1:] = np.cumsum(np.cumsum(a, 0), 1); return s
 any_s = [sat(a) for a in any_g]; notall_s = [sat(~a) for a in all_g]
+# variant: "all" grid at twice the block size (block (i, j) of it is all-foreground iff its four children are)
+def coarsen(a):
+    h2, w2 = (a.shape[0] + 1) // 2, (a.shape[1] + 1) // 2
+    p_ = np.ones((h2 * 2, w2 * 2), bool); p_[:a.shape[0], :a.shape[1]] = a
+    return p_.reshape(h2, 2, w2, 2).all(axis=(1, 3))
+notall2_s = [sat(~coarsen(a)) for a in all_g]
+COARSE_ALL = len(sys.argv) > 1 and sys.argv[1] == "coarse_all"
 def boxsum(s, v0, u0, v1, u1):
     return s[v1 + 1, u1 + 1] - s[v0, u1 + 1] - s[v1 + 1, u0] + s[v0, u0]
 
@@ -53,7 +60,8 @@ for z0 in (400, 512, 640):
         area = []
         for c in range(4):
             na = boxsum(any_s[c], bv0[c], bu0[c], bv1[c], bu1[c])
-            nn = boxsum(notall_s[c], bv0[c], bu0[c], bv1[c], bu1[c])
+            nn = (boxsum(notall2_s[c], bv0[c] >> 1, bu0[c] >> 1, bv1[c] >> 1, bu1[c] >> 1) if COARSE_ALL
+                  else boxsum(notall_s[c], bv0[c], bu0[c], bv1[c], bu1[c]))
             rej = empty[c] | (na == 0)
             acc = ~rej & allin[c] & (nn == 0)
             dead |= rej
@@ -61,6 +69,6 @@ for z0 in (400, 512, 640):
             area.append(((bv1[c] - bv0[c] + 1) * (bu1[c] - bu0[c] + 1))[~empty[c]].mean())
         und = ~dead & need
         return dead.mean(), (~dead & ~need).mean(), und.mean(), np.mean(area)
-    for shape in ((1, 1, 64), (1, 2, 32), (1, 4, 16), (2, 2, 16), (1, 8, 8), (2, 4, 8), (4, 4, 4)):
+    for shape in ((1, 1, 64), (1, 4, 16)):
         d, a, u, ar = classify(shape)
         print("z0 %4d shape dz,dx,dy=%s  dead %.4f accepted %.4f undecided %.4f  mean box area %.1f blocks" % (z0, shape, d, a, u, ar), flush=True)

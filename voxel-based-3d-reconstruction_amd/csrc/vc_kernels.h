@@ -19,6 +19,25 @@ constexpr uint32_t kMaxCameras = 16;
 constexpr uint32_t kLutPad = 8192;          // voxels; every chunking below divides it
 constexpr uint64_t kEmptyBox = ~0ull;       // pixel box of a word with no in-image voxel
 
+// One camera's block grids cover only the word columns [w_lo, w_lo + cws) and block rows [v_lo, v_lo + ch)
+// that hold foreground (a silhouette fills a few percent of its image); outside them "any" and "all"
+// are zero by definition.  ch == 0: the camera sees no foreground at all.
+struct GridCam {
+    uint32_t off;               // first word of any[]; all[] follows at off + ch * cws
+    uint16_t w_lo, v_lo, cws, ch;
+};
+
+// The grid buffer starts with the cameras' descriptors (3 words each) so that kernels index them in LDS --
+// indexing the kernel-argument copy with a run-time camera number costs the compiler 48 VGPRs.
+constexpr uint32_t kGridHeader = 3 * kMaxCameras;
+__device__ __forceinline__ GridCam load_gridcam(const uint32_t *grids, uint32_t c)
+{
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readfirstlane((int)grids[3 * c]);          // c is wave-uniform
+    const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)grids[3 * c + 1]);
+    const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)grids[3 * c + 2]);
+    return {a, (uint16_t)b, (uint16_t)(b >> 16), (uint16_t)d, (uint16_t)(d >> 16)};
+}
+
 struct CarveParams {
     const double *xs, *ys, *zs;
     const uint32_t *maskbits;   // [C][mwords] of the active frame set
@@ -28,8 +47,9 @@ struct CarveParams {
     const uint64_t *tbox;       // [C][n_pad/64] pixel boxes of the tile words
     uint32_t tq;                // tile words per row quad = ny / 16
     uint32_t tile_whole;        // 64 % tq == 0: the 64 tile words of a wave are exactly one y-major group
-    const uint32_t *blockgrid;  // [2][C][gh][gws] per 2^gshift-pixel block: "any pixel foreground", then "every pixel foreground"
-    uint32_t gshift, gws, gh;   // block-grid geometry
+    const uint32_t *blockgrid;  // per camera (crop[c].off): any[ch][cws] then all[ch][cws], one bit per 2^gshift-pixel block
+    uint32_t gshift;            // block size of this frame set's grids
+    uint32_t grid_words;        // u32 words of descriptors + grids (what the hierarchical kernels stage in LDS)
     uint64_t *words;
     uint32_t *groupcnt;         // survivors per group of 64 words (kernels that know it write it)
     uint16_t *viewmask;
@@ -273,25 +293,34 @@ __global__ __launch_bounds__(kFirstBlock) void k_lut_first(const CarveParams p)
 // A word's pixel box against one camera's block grids.  0: no foreground block in the box -- none of
 // its voxels can pass; 2: every voxel lands inside the image (kBoxAllInside) and every block the box
 // touches is entirely foreground -- all of its voxels pass, no table or mask read needed; 1: undecided.
-// Conservative (block granularity); boxes taller than 8 or wider than 64 blocks are undecided.
+// Conservative (block granularity); boxes taller than 16 or wider than 64 blocks are undecided.
 constexpr uint64_t kBoxAllInside = 1ull << 63;    // flag in the box word (mask heights < 32768)
 
-__device__ __forceinline__ uint32_t box_test(const uint32_t *__restrict__ g_any, const uint32_t *__restrict__ g_all,
-                                             uint64_t bb, uint32_t gshift, uint32_t gws)
+__device__ __forceinline__ uint32_t box_test(const uint32_t *__restrict__ grids, const GridCam gc, uint64_t bb, uint32_t gshift)
 {
-    if (bb == kEmptyBox) return 0;
+    if (bb == kEmptyBox || gc.ch == 0) return 0;
     const uint32_t bu0 = (uint32_t)(bb & 0xffffu) >> gshift, bv0 = (uint32_t)((bb >> 16) & 0xffffu) >> gshift;
     const uint32_t bu1 = (uint32_t)((bb >> 32) & 0xffffu) >> gshift, bv1 = (uint32_t)((bb >> 48) & 0x7fffu) >> gshift;
-    if (bv1 - bv0 > 7u || bu1 - bu0 > 63u) return 1;
     const uint32_t w0 = bu0 >> 5, w1 = bu1 >> 5;
-    uint32_t any = 0, miss = 0;
-    for (uint32_t r = bv0; r <= bv1; ++r) {
-        for (uint32_t w = w0; w <= w1; ++w) {
+    const uint32_t cw_hi = (uint32_t)gc.w_lo + gc.cws - 1u, cv_hi = (uint32_t)gc.v_lo + gc.ch - 1u;
+    if (w1 < gc.w_lo || w0 > cw_hi || bv1 < gc.v_lo || bv0 > cv_hi) return 0;      // nowhere near the foreground
+    if (bv1 - bv0 > 15u || bu1 - bu0 > 63u) return 1;
+    const uint32_t r0 = bv0 > gc.v_lo ? bv0 : gc.v_lo, r1 = bv1 < cv_hi ? bv1 : cv_hi;
+    const uint32_t c0 = w0 > gc.w_lo ? w0 : gc.w_lo, c1 = w1 < cw_hi ? w1 : cw_hi;
+    const uint32_t *__restrict__ g_any = grids + gc.off;
+    const uint32_t *__restrict__ g_all = g_any + (uint32_t)gc.ch * gc.cws;
+    uint32_t any = 0;
+    uint32_t miss = (r0 != bv0 || r1 != bv1 || c0 != w0 || c1 != w1) ? 1u : 0u;    // part of the box lies outside the kept blocks
+#pragma nounroll
+    for (uint32_t r = r0; r <= r1; ++r) {
+#pragma nounroll
+        for (uint32_t w = c0; w <= c1; ++w) {
             uint32_t m = 0xffffffffu;
             if (w == w0) m &= 0xffffffffu << (bu0 & 31u);
             if (w == w1) m &= 0xffffffffu >> (31u - (bu1 & 31u));
-            any |= g_any[(size_t)r * gws + w] & m;
-            miss |= ~g_all[(size_t)r * gws + w] & m;
+            const uint32_t i = (r - gc.v_lo) * gc.cws + (w - gc.w_lo);
+            any |= g_any[i] & m;
+            miss |= ~g_all[i] & m;
         }
     }
     if (any == 0) return 0;
@@ -347,11 +376,10 @@ __device__ __forceinline__ void tile_store(const CarveParams &p, uint32_t g, uin
 template <int B, bool HIER, bool PAIR, bool TILE = false>
 __device__ __forceinline__ void lut_refine_body(const CarveParams &p, uint32_t vblock, uint32_t nblocks, uint32_t *s_grid)
 {
-    const uint32_t gridwords = p.C * p.gh * p.gws;
-    if (HIER) {                                                   // both grids into LDS, 16 bytes per lane (buffer padded to 16 B)
+    if (HIER) {                                                   // the grids into LDS, 16 bytes per lane (buffer padded to 16 B)
         const uint4 *src = reinterpret_cast<const uint4 *>(p.blockgrid);
         uint4 *dst = reinterpret_cast<uint4 *>(s_grid);
-        for (uint32_t i = threadIdx.x; i < (2 * gridwords + 3) / 4; i += kBlock) dst[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < (p.grid_words + 3) / 4; i += kBlock) dst[i] = src[i];
         __syncthreads();
     }
     const uint32_t lane = threadIdx.x & 63u;
@@ -378,8 +406,7 @@ __device__ __forceinline__ void lut_refine_body(const CarveParams &p, uint32_t v
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (q0 + k < p.C && cand) {
-                        const uint32_t *ga = s_grid + (size_t)p.order[q0 + k] * p.gh * p.gws;
-                        const uint32_t r = box_test(ga, ga + gridwords, bb[k], p.gshift, p.gws);
+                        const uint32_t r = box_test(s_grid, load_gridcam(s_grid, p.order[q0 + k]), bb[k], p.gshift);
                         cand = r != 0;
                         if (r == 1) need |= 1u << (q0 + k);
                     }
@@ -473,7 +500,7 @@ __device__ __forceinline__ void lut_refine_body(const CarveParams &p, uint32_t v
 template <int B, bool HIER, bool PAIR, bool TILE = false>
 __global__ __launch_bounds__(kBlock) void k_lut_refine(const CarveParams p)
 {
-    extern __shared__ uint32_t s_grid[];                          // HIER: [2][C][gh][gws]
+    extern __shared__ uint32_t s_grid[];                          // HIER: the cropped block grids of all cameras
     lut_refine_body<B, HIER, PAIR, TILE>(p, blockIdx.x, gridDim.x, s_grid);
 }
 
@@ -691,12 +718,11 @@ __device__ __forceinline__ uint64_t segment_box_f32(const CamDev &c, double xa, 
 template <bool TILE, int BOX>
 __global__ __launch_bounds__(kBlock) void k_carve_fused_hier(const CarveParams p)
 {
-    extern __shared__ uint32_t s_grid[];                          // [2][C][gh][gws]
-    const uint32_t gridwords = p.C * p.gh * p.gws;
+    extern __shared__ uint32_t s_grid[];                          // the cropped block grids of all cameras
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(p.blockgrid);
         uint4 *dst = reinterpret_cast<uint4 *>(s_grid);
-        for (uint32_t i = threadIdx.x; i < (2 * gridwords + 3) / 4; i += kBlock) dst[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < (p.grid_words + 3) / 4; i += kBlock) dst[i] = src[i];
         __syncthreads();
     }
     const uint32_t lane = threadIdx.x & 63u;
@@ -730,8 +756,7 @@ __global__ __launch_bounds__(kBlock) void k_carve_fused_hier(const CarveParams p
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (q0 + k < p.C && cand) {
-                        const uint32_t *ga = s_grid + (size_t)p.order[q0 + k] * p.gh * p.gws;
-                        const uint32_t r = box_test(ga, ga + gridwords, bb[k], p.gshift, p.gws);
+                        const uint32_t r = box_test(s_grid, load_gridcam(s_grid, p.order[q0 + k]), bb[k], p.gshift);
                         cand = r != 0;
                         if (r == 1) need |= 1u << (q0 + k);
                     }
@@ -745,8 +770,7 @@ __global__ __launch_bounds__(kBlock) void k_carve_fused_hier(const CarveParams p
                                              : segment_box(p.cam[c], xa, xb, ya, yb, Z, p.H, p.W);
                 uint32_t r = 1;
                 if (bb != kMaybeBox) {
-                    const uint32_t *ga = s_grid + (size_t)c * p.gh * p.gws;
-                    r = box_test(ga, ga + gridwords, bb, p.gshift, p.gws);
+                    r = box_test(s_grid, load_gridcam(s_grid, c), bb, p.gshift);
                 }
                 cand = r != 0;
                 if (r == 1) need |= 1u << q;
@@ -890,29 +914,68 @@ __global__ __launch_bounds__(kBlock) void k_tile_lut(const CarveParams p, const 
     }
 }
 
-// Two bits per block of 2^gshift x 2^gshift pixels of one frame set: "some pixel is foreground" and
-// "every pixel (inside the image) is foreground".  grid = [any: C][gh][gws] then [all: C][gh][gws].
+// Pixel bounding box of each camera's foreground: out[4c..] = u_min, u_max, v_min, v_max (u_min > u_max: none).
+// One workgroup per camera.
+__global__ __launch_bounds__(kBlock) void k_mask_bbox(const uint32_t *__restrict__ maskbits, uint32_t mwords, uint32_t H,
+                                                      uint32_t W, uint32_t *__restrict__ out)
+{
+    __shared__ uint32_t s[4];
+    const uint32_t c = blockIdx.x;
+    if (threadIdx.x == 0) { s[0] = 0xffffffffu; s[1] = 0; s[2] = 0xffffffffu; s[3] = 0; }
+    __syncthreads();
+    const uint32_t *mb = maskbits + (size_t)c * mwords;
+    uint32_t u0 = 0xffffffffu, u1 = 0, v0 = 0xffffffffu, v1 = 0;
+    for (uint32_t w = threadIdx.x; w < mwords; w += kBlock) {
+        uint32_t bits = mb[w];
+        while (bits) {
+            const uint32_t o = w * 32 + (uint32_t)__builtin_ctz(bits);
+            bits &= bits - 1;
+            if (o >= H * W) break;
+            const uint32_t v = o / W, u = o - v * W;
+            u0 = u < u0 ? u : u0; u1 = u > u1 ? u : u1;
+            v0 = v < v0 ? v : v0; v1 = v > v1 ? v : v1;
+        }
+    }
+    if (u0 != 0xffffffffu) { atomicMin(&s[0], u0); atomicMax(&s[1], u1); atomicMin(&s[2], v0); atomicMax(&s[3], v1); }
+    __syncthreads();
+    if (threadIdx.x < 4) out[4 * c + threadIdx.x] = s[threadIdx.x];
+}
+
+// Two bits per block of 2^gshift x 2^gshift pixels, only for the blocks of crop[c] (see GridCam): "some pixel
+// is foreground" and "every pixel (inside the image) is foreground".  The buffer is zeroed before.
+struct GridBuild {
+    uint32_t H, W, mwords, gshift;
+    GridCam crop[kMaxCameras];
+};
+
 __global__ __launch_bounds__(kBlock) void k_blockgrid(const uint32_t *__restrict__ maskbits, uint32_t *__restrict__ grid,
-                                                      uint32_t C, uint32_t H, uint32_t W, uint32_t mwords,
-                                                      uint32_t gshift, uint32_t gws, uint32_t gh)
+                                                      const GridBuild p)
 {
     const uint32_t c = blockIdx.y;
-    const uint32_t gw = (W + (1u << gshift) - 1) >> gshift;
+    const GridCam gc = p.crop[c];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                   // the camera's descriptor, as load_gridcam reads it
+        grid[3 * c] = gc.off;
+        grid[3 * c + 1] = (uint32_t)gc.w_lo | ((uint32_t)gc.v_lo << 16);
+        grid[3 * c + 2] = (uint32_t)gc.cws | ((uint32_t)gc.ch << 16);
+    }
+    const uint32_t bw = (uint32_t)gc.cws * 32u;                  // block columns kept
     const uint32_t b = blockIdx.x * kBlock + threadIdx.x;
-    if (b >= gw * gh) return;
-    const uint32_t bv = b / gw, bu = b - bv * gw;
-    const uint32_t *mb = maskbits + (size_t)c * mwords;
+    if (b >= bw * gc.ch) return;
+    const uint32_t rv = b / bw, ru = b - rv * bw;
+    const uint32_t bv = gc.v_lo + rv, bu = (uint32_t)gc.w_lo * 32u + ru;
+    if ((bu << p.gshift) >= p.W || (bv << p.gshift) >= p.H) return;
+    const uint32_t *mb = maskbits + (size_t)c * p.mwords;
     bool any = false, all = true;
-    for (uint32_t y = bv << gshift; y < ((bv + 1) << gshift) && y < H; ++y)
-        for (uint32_t x = bu << gshift; x < ((bu + 1) << gshift) && x < W; ++x) {
-            const uint32_t o = y * W + x;
+    for (uint32_t y = bv << p.gshift; y < ((bv + 1) << p.gshift) && y < p.H; ++y)
+        for (uint32_t x = bu << p.gshift; x < ((bu + 1) << p.gshift) && x < p.W; ++x) {
+            const uint32_t o = y * p.W + x;
             const bool fg = (mb[o >> 5] >> (o & 31u)) & 1u;
             any = any || fg;
             all = all && fg;
         }
-    const size_t w = ((size_t)c * gh + bv) * gws + (bu >> 5);
-    if (any) atomicOr(&grid[w], 1u << (bu & 31u));
-    if (all) atomicOr(&grid[(size_t)C * gh * gws + w], 1u << (bu & 31u));
+    const uint32_t w = gc.off + rv * gc.cws + (ru >> 5);
+    if (any) atomicOr(&grid[w], 1u << (ru & 31u));
+    if (all) atomicOr(&grid[w + (uint32_t)gc.ch * gc.cws], 1u << (ru & 31u));
 }
 
 __global__ __launch_bounds__(kBlock) void k_project(const CamDev cam, const double *__restrict__ xyz,

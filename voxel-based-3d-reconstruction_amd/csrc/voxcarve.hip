@@ -90,7 +90,9 @@ struct Slot {
     DevBuf<uint32_t> frames;    // [C][H*W] BGRX, one dword per pixel
     std::vector<uint8_t> have_frame;
     bool have_masks = false;
-    DevBuf<uint32_t> grid;      // [C][gh][gws] foreground-block bits (hierarchical LUT carve)
+    DevBuf<uint32_t> grid;      // cropped block grids of all cameras (hierarchical kernels stage them in LDS)
+    GridCam crop[VC_MAX_CAMERAS];
+    uint32_t gshift = 2, grid_words = 0;
     uint32_t order[VC_MAX_CAMERAS];  // most selective camera first (k_estimate)
     bool order_valid = false;
 };
@@ -169,11 +171,14 @@ struct vc_ctx {
     DevBuf<uint64_t> d_tbox;         // pixel boxes of the tile words
     bool tile_valid = false;
     bool bbox_valid = false, tbox_valid = false;   // boxes match the grid, slab and cameras (also built without a table)
+    int grid_lds_kb = 16;            // LDS budget of a frame set's block grids (picks their resolution at upload)
+    int grid_min_shift = 1;          // finest block: 2^shift pixels
     int lut_tile = 1;                // hierarchical LUT kernel on tile words (needs nx % 4 == 0, ny % 64 == 0)
     int fused_tile = 1;              // the same word shape for the hierarchical table-free kernel
     int fused_f32box = 1;            // its word boxes from float32 intervals after a float64 rigid transform ...
     int fused_boxes = 1;             // ... or read from boxes reduced once from the exact pixels (no table involved)
-    uint32_t gshift = 2, gws = 1, gh = 1;   // block grid geometry for H x W
+    DevBuf<uint32_t> d_mbbox;        // per camera foreground pixel bounding box (k_mask_bbox)
+    uint32_t *h_mbbox = nullptr;     // pinned, 4 per camera
     bool lut_valid = false;
     DevBuf<uint32_t> d_est;          // per-camera pass counts of k_estimate
     uint32_t *h_est = nullptr;       // pinned, VC_MAX_CAMERAS
@@ -290,7 +295,54 @@ void fill_params(const vc_ctx *ctx, CarveParams &p)
     p.bbox = ctx->d_bbox.ptr;
     p.lut_tile = ctx->d_lut_tile.ptr; p.tbox = ctx->d_tbox.ptr; p.tq = ctx->ny / 16;
     p.tile_whole = (p.tq != 0 && 64 % p.tq == 0) ? 1u : 0u;
-    p.gshift = ctx->gshift; p.gws = ctx->gws; p.gh = ctx->gh;
+}
+
+// Block grids of a frame set.  A silhouette covers a few percent of its image, so only the blocks
+// around each camera's foreground are kept (GridCam); what that saves goes into resolution: the
+// finest power-of-two block whose grids of all cameras fit grid_lds_kb (16 KB: room for 8 workgroups
+// per CU, and the hierarchical kernels' LDS fill becomes a non-event).
+
+int build_block_grids(vc_ctx *ctx, Slot &s)
+{
+    const uint32_t C = ctx->C, H = ctx->H, W = ctx->W;
+    VC_TRY(ensure(ctx, ctx->d_mbbox, 4 * VC_MAX_CAMERAS));
+    if (!ctx->h_mbbox)
+        VC_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_mbbox), sizeof(uint32_t) * 4 * VC_MAX_CAMERAS, hipHostMallocDefault));
+    hipLaunchKernelGGL(k_mask_bbox, dim3(C), dim3(kBlock), 0, ctx->stream, s.bits.ptr, ctx->mwords, H, W, ctx->d_mbbox.ptr);
+    VC_HIP(ctx, hipGetLastError());
+    VC_HIP(ctx, hipMemcpyAsync(ctx->h_mbbox, ctx->d_mbbox.ptr, sizeof(uint32_t) * 4 * C, hipMemcpyDeviceToHost, ctx->stream));
+    VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    uint32_t total = 0, maxblocks = 0;
+    for (s.gshift = (uint32_t)ctx->grid_min_shift; s.gshift < 15; ++s.gshift) {
+        total = kGridHeader; maxblocks = 0;
+        for (uint32_t c = 0; c < C; ++c) {
+            GridCam &g = s.crop[c];
+            const uint32_t *b = ctx->h_mbbox + 4 * c;            // u_min, u_max, v_min, v_max
+            g.off = total; g.w_lo = g.v_lo = g.cws = g.ch = 0;
+            if (b[0] > b[1]) continue;                           // no foreground in this camera
+            g.w_lo = (uint16_t)((b[0] >> s.gshift) >> 5);
+            g.cws = (uint16_t)(((b[1] >> s.gshift) >> 5) - g.w_lo + 1);
+            g.v_lo = (uint16_t)(b[2] >> s.gshift);
+            g.ch = (uint16_t)((b[3] >> s.gshift) - g.v_lo + 1);
+            total += 2u * g.cws * g.ch;
+            const uint32_t blocks = 32u * g.cws * g.ch;
+            maxblocks = blocks > maxblocks ? blocks : maxblocks;
+        }
+        if ((size_t)total * sizeof(uint32_t) <= (size_t)ctx->grid_lds_kb * 1024) break;
+    }
+    s.grid_words = total;
+    VC_TRY(ensure(ctx, s.grid, (size_t)total + 4));               // + padding: kernels copy it 16 bytes at a time
+    VC_HIP(ctx, hipMemsetAsync(s.grid.ptr, 0, ((size_t)total + 4) * sizeof(uint32_t), ctx->stream));
+    if (maxblocks) {
+        GridBuild p;
+        memset(&p, 0, sizeof p);
+        p.H = H; p.W = W; p.mwords = ctx->mwords; p.gshift = s.gshift;
+        memcpy(p.crop, s.crop, sizeof(GridCam) * C);
+        hipLaunchKernelGGL(k_blockgrid, dim3((maxblocks + kBlock - 1) / kBlock, C), dim3(kBlock), 0, ctx->stream, s.bits.ptr,
+                           s.grid.ptr, p);
+        VC_HIP(ctx, hipGetLastError());
+    }
+    return VC_OK;
 }
 
 int slot_at(vc_ctx *ctx, uint32_t slot, Slot **out)
@@ -585,7 +637,8 @@ int vc_destroy(vc_ctx *ctx)
     if (ctx->h_xtotal) (void)hipHostFree(ctx->h_xtotal);
     if (ctx->h_total) (void)hipHostFree(ctx->h_total);
     if (ctx->h_est) (void)hipHostFree(ctx->h_est);
-    release(ctx->d_est);
+    release(ctx->d_est); release(ctx->d_mbbox);
+    if (ctx->h_mbbox) (void)hipHostFree(ctx->h_mbbox);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
     for (int i = 0; i < 4; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -669,13 +722,6 @@ int vc_set_cameras(vc_ctx *ctx, uint32_t C, const double *K9, const double *dist
     const bool reshaped = (C != ctx->C || H != ctx->H || W != ctx->W);
     ctx->C = C; ctx->H = H; ctx->W = W;
     ctx->mwords = (uint32_t)(((uint64_t)H * W + 31) / 32);
-    // foreground-block grids (any / all): finest power-of-two block whose 2 C grids fit 48 KB of LDS
-    for (ctx->gshift = 2; ctx->gshift < 12; ++ctx->gshift) {
-        const uint32_t gw = (W + (1u << ctx->gshift) - 1) >> ctx->gshift;
-        ctx->gh = (H + (1u << ctx->gshift) - 1) >> ctx->gshift;
-        ctx->gws = (gw + 31) / 32;
-        if (2 * (size_t)C * ctx->gh * ctx->gws * sizeof(uint32_t) <= 48 * 1024) break;
-    }
     ctx->have_cams = true;
     if (reshaped) {
         (void)hipSetDevice(ctx->device);
@@ -717,16 +763,7 @@ int vc_upload_masks(vc_ctx *ctx, uint32_t slot, const uint8_t *masks)
     hipLaunchKernelGGL(k_pack_masks, grid, dim3(kBlock), 0, ctx->stream, ctx->d_stage.ptr, s->bits.ptr,
                        ctx->C, (uint32_t)HW, ctx->mwords);
     VC_HIP(ctx, hipGetLastError());
-    {
-        const size_t gwords = 2 * (size_t)ctx->C * ctx->gh * ctx->gws;
-        VC_TRY(ensure(ctx, s->grid, gwords + 4));                 // + padding: kernels copy it 16 bytes at a time
-        VC_HIP(ctx, hipMemsetAsync(s->grid.ptr, 0, gwords * sizeof(uint32_t), ctx->stream));
-        const uint32_t gw = (ctx->W + (1u << ctx->gshift) - 1) >> ctx->gshift;
-        dim3 gg((gw * ctx->gh + kBlock - 1) / kBlock, ctx->C);
-        hipLaunchKernelGGL(k_blockgrid, gg, dim3(kBlock), 0, ctx->stream, s->bits.ptr, s->grid.ptr, ctx->C, ctx->H, ctx->W,
-                           ctx->mwords, ctx->gshift, ctx->gws, ctx->gh);
-        VC_HIP(ctx, hipGetLastError());
-    }
+    VC_TRY(build_block_grids(ctx, *s));
     VC_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.h2d_ms, ctx->ev[0], ctx->ev[1]));
@@ -899,6 +936,7 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     p.maskbits = s.bits.ptr;
     p.lut = ctx->d_lut.ptr;
     p.blockgrid = s.grid.ptr;
+    p.gshift = s.gshift; p.grid_words = s.grid_words;
     p.words = sb.words.ptr;
     p.groupcnt = sb.groupcnt.ptr;
     p.viewmask = ctx->d_viewmask.ptr;
@@ -935,7 +973,7 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
         const dim3 grid((uint32_t)(want < gmax ? want : gmax));
         if (mode == VC_MODE_LUT && ctx->lut_hier) {
             // one launch: word-level rejection by pixel box x foreground-block grid, exact test for the rest
-            const size_t lds = (2 * (size_t)ctx->C * ctx->gh * ctx->gws + 4) * sizeof(uint32_t);
+            const size_t lds = ((size_t)s.grid_words + 4) * sizeof(uint32_t);
             const uint64_t groups = p.n_pad / 4096;
             const uint64_t rwant = (groups + 3) / 4;
             const uint64_t rmax = 256ull * (uint64_t)ctx->hier_blocks_per_cu;
@@ -977,7 +1015,7 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
             else hipLaunchKernelGGL((k_lut_refine<16, false, false>), rgrid, block, 0, ctx->stream, p);
         }
         else if (ctx->ny % 64 == 0 && ctx->fused_hier) {
-            const size_t lds = (2 * (size_t)ctx->C * ctx->gh * ctx->gws + 4) * sizeof(uint32_t);
+            const size_t lds = ((size_t)s.grid_words + 4) * sizeof(uint32_t);
             const uint64_t groups = p.n_pad / 4096;
             const uint64_t rwant = (groups + 3) / 4;
             const uint64_t rmax = 256ull * (uint64_t)ctx->hier_blocks_per_cu;
@@ -1210,6 +1248,8 @@ int vc_set_option(vc_ctx *ctx, const char *name, int value)
     else if (k == "fused_hier") ctx->fused_hier = value != 0;
     else if (k == "emit_lanes") ctx->emit_lanes = value != 0;
     else if (k == "lut_tile") ctx->lut_tile = value != 0;
+    else if (k == "grid_lds_kb" && value >= 1 && value <= 64) ctx->grid_lds_kb = value;
+    else if (k == "grid_min_shift" && value >= 0 && value <= 8) ctx->grid_min_shift = value;
     else if (k == "fused_tile") ctx->fused_tile = value != 0;
     else if (k == "fused_f32box") ctx->fused_f32box = value != 0;
     else if (k == "fused_boxes") ctx->fused_boxes = value != 0;
