@@ -436,6 +436,17 @@ def test_rccl_allgather_single_rank(eng, cams, masks, frames):
         for a, b in zip(got, want):
             assert np.array_equal(a, b), mode
     eng.set_option("gather_sync", 1)
+    # a rank whose slab is empty (work-balanced bounds can produce one) still takes part in the collectives
+    eng.set_slab(7, 7)
+    for mode in ("fused",):
+        assert eng.carve(mode=mode, records=False) == 0
+        counts, total = eng.allgather()
+        assert counts.tolist() == [0] and total == 0 and eng.fetch_gathered().size == 0
+        eng.carve_begin(mode=mode, records=False)
+        eng.carve_begin(mode=mode, records=False)
+        assert eng.carve_end() == 0 and eng.allgather()[1] == 0
+        assert eng.carve_end() == 0 and eng.allgather()[1] == 0
+    eng.set_slab(0, 64)
     eng.comm_destroy()
 
 
