@@ -1,17 +1,18 @@
 """Stability: many steps, many contexts; device memory must come back."""
-import os, sys, time, subprocess
+import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import voxcarve, fixtures_util as fx
 
+_hip = __import__("ctypes").CDLL("libamdhip64.so")
+
 def used_mb():
-    out = subprocess.run(["rocm-smi", "--showmeminfo", "vram", "--csv"], capture_output=True, text=True).stdout
-    for line in out.splitlines():
-        parts = line.split(",")
-        if len(parts) >= 3 and parts[0].startswith("card"):
-            return int(parts[2]) / 1e6
-    return float("nan")
+    """Device memory in use (hipMemGetInfo; rocm-smi's figure lags behind frees by seconds)."""
+    import ctypes
+    f, t = ctypes.c_size_t(), ctypes.c_size_t()
+    _hip.hipMemGetInfo(ctypes.byref(f), ctypes.byref(t))
+    return (t.value - f.value) / 1e6
 
 cams, masks = fx.golden_cameras(), fx.golden_masks()
 frames = fx.synthetic_frames(4, *masks[0].shape)
