@@ -68,6 +68,8 @@ struct EmitParams {
     const uint32_t *frame;      // colour camera's image as one BGRX dword per pixel (or null)
     const int32_t *lut;         // colour camera's packed table (FROM_LUT), else null
     const uint64_t *words;
+    const uint32_t *busylist;   // k_emit_busy: the groups with survivors; busycount[0] of them
+    const uint32_t *busycount;
     const uint64_t *entries;    // INDIRECT expansion: {bits, global index of bit 0} pairs instead of words
     const uint32_t *groupcnt;   // survivors per group
     const uint32_t *groupoff;   // exclusive scan of groupcnt inside each scan block
@@ -1087,38 +1089,50 @@ __global__ __launch_bounds__(kBlock) void k_count_entries(const uint64_t *__rest
 // The grand total goes to device memory AND straight to a page-locked host word (no copy kernel).
 __global__ __launch_bounds__(kScanBlock) void k_scan_groups(const uint32_t *__restrict__ cnt, uint32_t ngroups,
                                                             uint32_t *__restrict__ off, uint64_t *__restrict__ blocksum,
-                                                            uint64_t *__restrict__ blockoff, uint64_t *__restrict__ total_host)
+                                                            uint64_t *__restrict__ blockoff, uint64_t *__restrict__ total_host,
+                                                            uint32_t *__restrict__ busyoff, uint32_t *__restrict__ busysum,
+                                                            uint32_t *__restrict__ busyblock)
 {
-    __shared__ uint32_t wsum[kScanBlock / 64];
+    __shared__ uint32_t wsum[kScanBlock / 64], wbusy[kScanBlock / 64];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const uint32_t i = blockIdx.x * kScanBlock + t;
     const uint32_t c = (i < ngroups) ? cnt[i] : 0u;      // <= 4096 each: a block total fits u32
     const uint32_t incl = wave_inclusive_scan(c, lane);
-    if (lane == 63) wsum[wave] = incl;
+    // busyoff != null: the same scan over "group has survivors", for the list of busy groups (k_busy_list)
+    const uint32_t f = (busyoff && c) ? 1u : 0u;
+    const uint32_t fincl = busyoff ? wave_inclusive_scan(f, lane) : 0u;
+    if (lane == 63) { wsum[wave] = incl; wbusy[wave] = fincl; }
     __syncthreads();
-    uint32_t before = 0, total = 0;
+    uint32_t before = 0, total = 0, fbefore = 0, ftotal = 0;
 #pragma unroll
     for (uint32_t k = 0; k < kScanBlock / 64; ++k) {
-        const uint32_t s = wsum[k];
-        if (k < wave) before += s;
-        total += s;
+        const uint32_t s = wsum[k], fs = wbusy[k];
+        if (k < wave) { before += s; fbefore += fs; }
+        total += s; ftotal += fs;
     }
-    if (i < ngroups) off[i] = before + incl - c;
+    if (i < ngroups) {
+        off[i] = before + incl - c;
+        if (busyoff) busyoff[i] = fbefore + fincl - f;
+    }
     if (t == 0) {
         blocksum[blockIdx.x] = total;
+        if (busyoff) busysum[blockIdx.x] = ftotal;
         if (gridDim.x == 1) {
             blockoff[0] = 0;
             blockoff[1] = total;
             *total_host = total;
+            if (busyoff) { busyblock[0] = 0; busyblock[1] = ftotal; }
         }
     }
 }
 
 // Level 2: exclusive scan of the (at most kScanBlock) block sums; blockoff[nblocks] = total.
 __global__ __launch_bounds__(kScanBlock) void k_scan_blocks(const uint64_t *__restrict__ blocksum, uint32_t nblocks,
-                                                            uint64_t *__restrict__ blockoff, uint64_t *__restrict__ total_host)
+                                                            uint64_t *__restrict__ blockoff, uint64_t *__restrict__ total_host,
+                                                            const uint32_t *__restrict__ busysum, uint32_t *__restrict__ busyblock)
 {
     __shared__ uint64_t wsum[kScanBlock / 64];
+    __shared__ uint32_t wbusy[kScanBlock / 64];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const uint64_t c = (t < nblocks) ? blocksum[t] : 0ull;
     uint64_t incl = c;
@@ -1127,20 +1141,37 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_blocks(const uint64_t *__re
         const uint64_t o = __shfl_up(incl, d);
         if (lane >= (uint32_t)d) incl += o;
     }
-    if (lane == 63) wsum[wave] = incl;
+    const uint32_t f = (busysum && t < nblocks) ? busysum[t] : 0u;     // busy groups of the block: <= 1024
+    const uint32_t fincl = busysum ? wave_inclusive_scan(f, lane) : 0u;
+    if (lane == 63) { wsum[wave] = incl; wbusy[wave] = fincl; }
     __syncthreads();
     uint64_t before = 0, total = 0;
+    uint32_t fbefore = 0, ftotal = 0;
 #pragma unroll
     for (uint32_t k = 0; k < kScanBlock / 64; ++k) {
         const uint64_t s = wsum[k];
-        if (k < wave) before += s;
-        total += s;
+        const uint32_t fs = wbusy[k];
+        if (k < wave) { before += s; fbefore += fs; }
+        total += s; ftotal += fs;
     }
-    if (t < nblocks) blockoff[t] = before + incl - c;
+    if (t < nblocks) {
+        blockoff[t] = before + incl - c;
+        if (busysum) busyblock[t] = fbefore + fincl - f;
+    }
     if (t == 0) {
         blockoff[nblocks] = total;
         *total_host = total;
+        if (busysum) busyblock[nblocks] = ftotal;
     }
+}
+
+// The groups that have survivors, ascending: what the record expansion iterates over (5 of 6 groups have none).
+__global__ __launch_bounds__(kBlock) void k_busy_list(const uint32_t *__restrict__ cnt, uint32_t ngroups,
+                                                      const uint32_t *__restrict__ busyoff, const uint32_t *__restrict__ busyblock,
+                                                      uint32_t *__restrict__ list)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < ngroups && cnt[i]) list[busyblock[i / kScanBlock] + busyoff[i]] = i;
 }
 
 // BGR bytes -> one BGRX dword per pixel, so a colour sample is a single aligned load.
@@ -1252,13 +1283,9 @@ __global__ __launch_bounds__(kBlock) void k_emit_words(const EmitParams p)
 // sparse words (the hull's words are dense: ~44 of 64 bits).  EB words are expanded together.
 // INDIRECT: the "words" are gathered {bits, base} entries of all ranks (p.n = 64 x entries, p.lut =
 // the colour camera's table over the WHOLE grid, p.z0 = p.i0 = 0): voxel index = base + lane.
-template <bool FROM_LUT, bool ALLSEEN, int EB, bool INDIRECT = false>
-__global__ __launch_bounds__(kBlock) void k_emit_lanes(const EmitParams p)
+template <bool FROM_LUT, bool ALLSEEN, int EB, bool INDIRECT>
+__device__ __forceinline__ void emit_group_lanes(const EmitParams &p, const uint32_t g, const uint32_t lane)
 {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t g = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
-    if (g >= p.ngroups) return;
-    if (p.groupcnt[g] == 0) return;
     const uint64_t nwords = (p.n + 63) >> 6;
     const uint64_t out0 = p.blockoff[g / kScanBlock] + p.groupoff[g];
     const uint64_t gw = (uint64_t)g * kGroupWords;
@@ -1325,6 +1352,29 @@ __global__ __launch_bounds__(kBlock) void k_emit_lanes(const EmitParams p)
             }
         }
     }
+}
+
+template <bool FROM_LUT, bool ALLSEEN, int EB, bool INDIRECT = false>
+__global__ __launch_bounds__(kBlock) void k_emit_lanes(const EmitParams p)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t g = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
+    if (g >= p.ngroups) return;
+    if (p.groupcnt[g] == 0) return;
+    emit_group_lanes<FROM_LUT, ALLSEEN, EB, INDIRECT>(p, g, lane);
+}
+
+// The same expansion driven by the list of busy groups (k_busy_list): a fixed grid of waves strides over
+// it, so no wave is launched only to find its group empty (5 of 6 are).
+template <bool FROM_LUT, bool ALLSEEN, int EB>
+__global__ __launch_bounds__(kBlock) void k_emit_busy(const EmitParams p)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t w = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
+    const uint32_t nwaves = gridDim.x * (kBlock / 64);
+    const uint32_t nbusy = p.busycount[0];
+    for (uint32_t t = w; t < nbusy; t += nwaves)
+        emit_group_lanes<FROM_LUT, ALLSEEN, EB, false>(p, p.busylist[t], lane);
 }
 
 }  // namespace vc

@@ -131,6 +131,8 @@ struct StepBuf {
     bool allseen = false, want_vm = false, has_first = false;
     bool no_records = false;                 // VC_FLAG_NO_RECORDS: occupancy words + count only
     bool sparse_words = false;               // words of groups with groupcnt == 0 were left unwritten
+    DevBuf<uint32_t> busyoff, busysum, busyblock, busylist;   // the groups with survivors, listed by the scan
+    bool busy = false;
     // compact exchange form of this step: non-zero words as {bits, global index of bit 0} pairs
     DevBuf<uint64_t> ent, mine, counts;      // pairs | {entries, survivors} of this rank | of all ranks
     uint64_t *h_counts = nullptr;            // pinned, 2 per rank
@@ -193,6 +195,8 @@ struct vc_ctx {
     int hier_blocks_per_cu = 48;     // hierarchical kernel: oversubscribed grid, the dispatcher balances uneven groups
     int refine_pair = 1;             // hierarchical LUT kernel: two cameras per dependent round trip
     int emit_lanes = 1;              // record expansion: lanes = voxels of a word (1) or lanes = survivors (0)
+    int emit_busy = 1;               // ... driven by the list of busy groups (grids of >= kBusyListMinGroups groups)
+    int emit_waves_per_cu = 128;     // waves of that launch per CU
     int fused_hier = 1;              // VC_MODE_FUSED: interval-arithmetic word rejection (needs ny % 64 == 0)
     int lut_hier = 1;                // VC_MODE_LUT: hierarchical kernel (boxes + block grid) instead of stream + refine
     DevBuf<uint16_t> d_viewmask;
@@ -365,6 +369,15 @@ int launch_emit(vc_ctx *ctx, StepBuf &sb, hipStream_t st)
 {
     const EmitParams &e = sb.emit;
     const dim3 eg((e.ngroups + 3) / 4), block(kBlock);
+    if (sb.busy && ctx->emit_lanes) {
+        const dim3 bg(256u * (uint32_t)ctx->emit_waves_per_cu / 4u);
+        if (e.lut && sb.allseen) hipLaunchKernelGGL((k_emit_busy<true, true, 8>), bg, block, 0, st, e);
+        else if (e.lut) hipLaunchKernelGGL((k_emit_busy<true, false, 8>), bg, block, 0, st, e);
+        else if (sb.allseen) hipLaunchKernelGGL((k_emit_busy<false, true, 4>), bg, block, 0, st, e);
+        else hipLaunchKernelGGL((k_emit_busy<false, false, 4>), bg, block, 0, st, e);
+        VC_HIP(ctx, hipGetLastError());
+        return VC_OK;
+    }
     if (ctx->emit_lanes) {
         if (e.lut && sb.allseen) hipLaunchKernelGGL((k_emit_lanes<true, true, 8>), eg, block, 0, st, e);
         else if (e.lut) hipLaunchKernelGGL((k_emit_lanes<true, false, 8>), eg, block, 0, st, e);
@@ -380,6 +393,7 @@ int launch_emit(vc_ctx *ctx, StepBuf &sb, hipStream_t st)
 }
 
 constexpr int VC_MAX_RANKS = 64;
+constexpr uint32_t kBusyListMinGroups = 16384;   // below 64 M voxels a wave per group is as fast and one launch shorter
 constexpr uint32_t kMaxScanBlocks = 1024;  // 2^32 voxels / 4096 per group / 1024 groups per scan block
 constexpr int kSub = 4;                    // 64-voxel sub-chunks per wavefront chunk (fused kernel)
 constexpr size_t kLdsBytes = 160 * 1024;   // LDS per CU on gfx950
@@ -391,10 +405,12 @@ int scan_counts(vc_ctx *ctx, const uint32_t *cnt, uint32_t ngroups, uint32_t *of
                 uint64_t *total_host)
 {
     const uint32_t nscan = (ngroups + kScanBlock - 1) / kScanBlock;
-    hipLaunchKernelGGL(k_scan_groups, dim3(nscan), dim3(kScanBlock), 0, ctx->stream, cnt, ngroups, off, bsum, boff, total_host);
+    hipLaunchKernelGGL(k_scan_groups, dim3(nscan), dim3(kScanBlock), 0, ctx->stream, cnt, ngroups, off, bsum, boff, total_host,
+                       (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
     VC_HIP(ctx, hipGetLastError());
     if (nscan > 1) {
-        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(kScanBlock), 0, ctx->stream, bsum, nscan, boff, total_host);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(kScanBlock), 0, ctx->stream, bsum, nscan, boff, total_host,
+                           (const uint32_t *)nullptr, (uint32_t *)nullptr);
         VC_HIP(ctx, hipGetLastError());
     }
     return VC_OK;
@@ -624,6 +640,7 @@ int vc_destroy(vc_ctx *ctx)
     for (StepBuf &b : ctx->sb) {
         release(b.words); release(b.groupcnt); release(b.groupoff); release(b.blocksum); release(b.blockoff); release(b.records);
         release(b.ent); release(b.mine); release(b.counts);
+        release(b.busyoff); release(b.busysum); release(b.busyblock); release(b.busylist);
         if (b.h_counts) (void)hipHostFree(b.h_counts);
         if (b.h_total) (void)hipHostFree(b.h_total);
         if (b.e0) (void)hipEventDestroy(b.e0);
@@ -1066,11 +1083,26 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
                            sb.groupcnt.ptr);
         VC_HIP(ctx, hipGetLastError());
     }
+    // the expansion of a large grid iterates over the list of groups that have survivors, made by the same scan
+    sb.busy = ctx->emit_lanes && !sb.no_records && (ctx->emit_busy == 2 || (ctx->emit_busy == 1 && ngroups >= kBusyListMinGroups));
+    if (sb.busy) {
+        VC_TRY(ensure(ctx, sb.busyoff, ngroups));
+        VC_TRY(ensure(ctx, sb.busylist, ngroups));
+        VC_TRY(ensure(ctx, sb.busysum, kMaxScanBlocks));
+        VC_TRY(ensure(ctx, sb.busyblock, kMaxScanBlocks + 1));
+    }
     hipLaunchKernelGGL(k_scan_groups, dim3(nscan), dim3(kScanBlock), 0, s2, sb.groupcnt.ptr, ngroups, sb.groupoff.ptr,
-                       sb.blocksum.ptr, sb.blockoff.ptr, sb.h_total);
+                       sb.blocksum.ptr, sb.blockoff.ptr, sb.h_total, sb.busy ? sb.busyoff.ptr : nullptr, sb.busysum.ptr,
+                       sb.busyblock.ptr);
     VC_HIP(ctx, hipGetLastError());
     if (nscan > 1) {
-        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(kScanBlock), 0, s2, sb.blocksum.ptr, nscan, sb.blockoff.ptr, sb.h_total);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(kScanBlock), 0, s2, sb.blocksum.ptr, nscan, sb.blockoff.ptr, sb.h_total,
+                           sb.busy ? (const uint32_t *)sb.busysum.ptr : nullptr, sb.busyblock.ptr);
+        VC_HIP(ctx, hipGetLastError());
+    }
+    if (sb.busy) {
+        hipLaunchKernelGGL(k_busy_list, dim3(grid_for(ngroups)), block, 0, s2, sb.groupcnt.ptr, ngroups, sb.busyoff.ptr,
+                           sb.busyblock.ptr, sb.busylist.ptr);
         VC_HIP(ctx, hipGetLastError());
     }
 
@@ -1090,6 +1122,7 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     }
     e.records = sb.records.ptr;
     e.capacity = sb.records.cap;
+    e.busylist = sb.busylist.ptr; e.busycount = sb.busyblock.ptr ? sb.busyblock.ptr + nscan : nullptr;
     if (!sb.no_records) VC_TRY(launch_emit(ctx, sb, s2));
     if (auto_exchange) {
         VC_TRY(enqueue_pack(ctx, sb));
@@ -1247,6 +1280,8 @@ int vc_set_option(vc_ctx *ctx, const char *name, int value)
     else if (k == "lut_hier") ctx->lut_hier = value != 0;
     else if (k == "fused_hier") ctx->fused_hier = value != 0;
     else if (k == "emit_lanes") ctx->emit_lanes = value != 0;
+    else if (k == "emit_busy" && value >= 0 && value <= 2) ctx->emit_busy = value;          // 0 never, 1 large grids, 2 always
+    else if (k == "emit_waves_per_cu" && value >= 4 && value <= 1024) ctx->emit_waves_per_cu = value;
     else if (k == "lut_tile") ctx->lut_tile = value != 0;
     else if (k == "grid_lds_kb" && value >= 1 && value <= 64) ctx->grid_lds_kb = value;
     else if (k == "grid_min_shift" && value >= 0 && value <= 8) ctx->grid_min_shift = value;
