@@ -196,7 +196,7 @@ struct vc_ctx {
     int refine_pair = 1;             // hierarchical LUT kernel: two cameras per dependent round trip
     int emit_lanes = 1;              // record expansion: lanes = voxels of a word (1) or lanes = survivors (0)
     int emit_busy = 1;               // ... driven by the list of busy groups (grids of >= kBusyListMinGroups groups)
-    int emit_waves_per_cu = 128;     // waves of that launch per CU
+    int emit_waves_per_cu = 256;     // waves of that launch per CU (a wave strides over the list when there are more busy groups)
     int fused_hier = 1;              // VC_MODE_FUSED: interval-arithmetic word rejection (needs ny % 64 == 0)
     int lut_hier = 1;                // VC_MODE_LUT: hierarchical kernel (boxes + block grid) instead of stream + refine
     DevBuf<uint16_t> d_viewmask;
