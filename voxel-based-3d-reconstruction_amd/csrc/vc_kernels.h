@@ -313,16 +313,32 @@ __device__ __forceinline__ uint32_t box_test(const uint32_t *__restrict__ grids,
     const uint32_t *__restrict__ g_all = g_any + (uint32_t)gc.ch * gc.cws;
     uint32_t any = 0;
     uint32_t miss = (r0 != bv0 || r1 != bv1 || c0 != w0 || c1 != w1) ? 1u : 0u;    // part of the box lies outside the kept blocks
-#pragma nounroll
-    for (uint32_t r = r0; r <= r1; ++r) {
-#pragma nounroll
-        for (uint32_t w = c0; w <= c1; ++w) {
-            uint32_t m = 0xffffffffu;
-            if (w == w0) m &= 0xffffffffu << (bu0 & 31u);
-            if (w == w1) m &= 0xffffffffu >> (31u - (bu1 & 31u));
-            const uint32_t i = (r - gc.v_lo) * gc.cws + (w - gc.w_lo);
+    const uint32_t m0 = 0xffffffffu << (bu0 & 31u), m1 = 0xffffffffu >> (31u - (bu1 & 31u));
+    if (c0 == c1 && r1 - r0 < 4u) {
+        // the common shape (a tile word's box: one grid word wide, up to 4 block rows): straight-line, no loop
+        uint32_t m = 0xffffffffu;
+        if (c0 == w0) m &= m0;
+        if (c0 == w1) m &= m1;
+        const uint32_t i0 = (r0 - gc.v_lo) * gc.cws + (c0 - gc.w_lo);
+        const uint32_t nr = r1 - r0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t i = i0 + (k <= nr ? k : nr) * gc.cws;         // rows past the box repeat its last row
             any |= g_any[i] & m;
             miss |= ~g_all[i] & m;
+        }
+    } else {
+#pragma nounroll
+        for (uint32_t r = r0; r <= r1; ++r) {
+#pragma nounroll
+            for (uint32_t w = c0; w <= c1; ++w) {
+                uint32_t m = 0xffffffffu;
+                if (w == w0) m &= m0;
+                if (w == w1) m &= m1;
+                const uint32_t i = (r - gc.v_lo) * gc.cws + (w - gc.w_lo);
+                any |= g_any[i] & m;
+                miss |= ~g_all[i] & m;
+            }
         }
     }
     if (any == 0) return 0;
