@@ -327,6 +327,11 @@ def main():
         t = tj.get("%s_%d_g%d" % (args.mode, G, grp.world))
         if t:
             roof["traffic"] = t
+            # the same launch priced by the bytes that really crossed the HBM interface (PMC) instead of the contract's
+            # algorithmic bytes: how busy the memory system is, as opposed to how much work was avoided
+            gbs = t["hbm_bytes"] / (roof["avg_launch_ms"] * 1e-3) / 1e9
+            roof["traffic_rate_gbs"] = round(gbs, 1)
+            roof["traffic_frac_of_peak"] = round(gbs / HBM_PEAK_GBS, 4)
         if roof_stream and tj.get("lut_stream_%d_g%d" % (G, grp.world)):
             roof_stream["traffic"] = tj["lut_stream_%d_g%d" % (G, grp.world)]
 
