@@ -1,10 +1,24 @@
 // gfx950 kernels of the carve path.  Host code and the C ABI: voxcarve.hip.
 //
-// Work decomposition: the slab's n voxels are numbered j = 0..n-1 in the reference's
-// order (y fastest, voxel_reconstruction.py:57).  A wavefront owns a CHUNK of KSUB x 64
-// consecutive voxels; sub-chunk k is one 64-voxel "word" whose survivor bits come out of a
-// single __ballot.  Cameras are visited most-selective first (order[]) and a sub-chunk
-// stops loading / projecting as soon as none of its 64 voxels can still pass.
+// The slab's n voxels are numbered j = 0..n-1 in the reference's order (y fastest,
+// voxel_reconstruction.py:57).  The unit of work is a WORD of 64 voxels whose survivor bits come out of
+// one __ballot, and a GROUP of 64 words (4096 voxels) is what one wavefront finishes per iteration and
+// what the ordered compaction counts and scans.  A word is 64 consecutive y ("y-line") or, where the
+// grid shape allows, a tile of 4 x-rows x 16 y (compact footprint, tighter pixel box); results always
+// leave the kernels as y-major words.
+//
+//   per frame set   k_pack_masks, k_morph2x2, k_mask_bbox, k_blockgrid, k_expand_frame, k_estimate
+//   per geometry    k_build_lut<TILE> (table and/or word boxes), k_tile_lut
+//   carve           k_lut_refine<B,HIER,PAIR,TILE>   hierarchical lookup-table kernel (default VC_MODE_LUT)
+//                   k_carve_fused_hier<TILE,BOX>     the same with the projection in-kernel (default VC_MODE_FUSED)
+//                   k_lut_first + k_lut_refine<.,false,.>   the table streamed without skipping (roofline_stream)
+//                   k_carve_fused<KSUB,NY64>, k_carve_generic<LUT,VM>   chunked / one thread per voxel (any shape,
+//                                                                     thresholds below C, camera bit masks)
+//   compaction      k_count_groups, k_scan_groups, k_scan_blocks, k_busy_list, k_emit_busy / k_emit_lanes / k_emit_words
+//   multi-GPU       k_count_nz, k_pack_entries, k_count_entries, k_emit_lanes<.,INDIRECT>, k_zero_dead_groups
+//
+// Cameras are visited most-selective first (order[]); every level stops as soon as nothing it covers can
+// still pass.  All projection arithmetic is float64 with contraction off (vc_device.h).
 #pragma once
 #include "vc_device.h"
 
