@@ -613,3 +613,51 @@ def test_index_width_at_the_u32_limit(eng, cams, masks, frames):
     assert m == int((idx >= 1000 * layer).sum()) and np.array_equal(tail, rec[idx >= 1000 * layer])
     with pytest.raises(VoxcarveError):
         eng.set_grid(2048, 2048, 1024)                         # 2^32 voxels: refused
+
+
+def _run_bench(args, nproc=1, timeout=300):
+    """bench.py in a child process (as the driver launches it); returns the parsed JSON line of rank 0."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable]
+    if nproc > 1:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+                "--master-port", "29577"]
+    cmd += [os.path.join(root, "bench.py"), "--gpus", str(nproc)] + args
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_contract_single_gpu(built):
+    """The JSON line the driver reads: keys, types, and the numbers that must hang together."""
+    d = _run_bench(["--grid", "256", "--steps", "7", "--warmup", "2", "--cpu-seconds", "1"])   # last step lands on frame set 0
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 7 and d["warmup"] == 2 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["unit"] == "Mvoxel-views/s" and "workload" in d["config"] and "model" not in d["config"]
+    vv = 256 ** 3 * 4
+    assert abs(d["value"] - vv / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.02
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma", "valu_f64") and r["peak"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert d["config"]["survivors"] == 461113                      # the 256^3 golden count: the bench ran the real path
+
+
+def test_bench_two_ranks_host_transport(built):
+    """The N > 1 flow of bench.py (work-balanced slab bounds, records-free steps, compact word exchange, expansion of
+    all ranks' words on the device) with two processes sharing this GPU; the exchange itself goes through gloo
+    because RCCL refuses two ranks on one device.  The gathered list must be the single-rank one."""
+    d = _run_bench(["--grid", "256", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--single-device",
+                    "--transport", "host"], nproc=2, timeout=600)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["cpu_baseline"] is None
+    assert "balanced" in d["config"]["split"] and "host" in d["config"]["exchange"]
+    # frame sets are rolled per step: the last timed step (index warmup + steps - 1 = 4 -> slot 0) is the unrolled set
+    assert d["config"]["survivors"] == 461113
+    for m in d["other_modes"].values():
+        assert m["survivors"] == 461113
