@@ -143,7 +143,22 @@ int vc_fetch_viewmask(vc_ctx *ctx, uint16_t *viewmask);
  * slab-local voxel j (consumer shape of assignment.py:143-146). */
 int vc_fetch_occupancy(vc_ctx *ctx, uint8_t *bits);
 
-/* Tuning knobs (launch geometry; never changes results): see voxcarve.hip vc_set_option. */
+/* Tuning knobs: which of the equivalent kernels runs and with what launch geometry; NEVER changes results
+ * (tests/test_gpu_parity.py runs every family against the oracle).  Defaults are the measured best on MI355X.
+ *   kernel choice   lut_hier (1)  hierarchical lookup-table kernel, 0 = stream the table (k_lut_first + refine)
+ *                   lut_tile, fused_tile (1)  words of 4 x-rows x 16 y where nx % 4 == 0 and ny % 64 == 0
+ *                   fused_hier (1), fused_boxes (1), fused_f32box (1)  table-free kernel: word rejection; boxes read /
+ *                                  bounded on the fly in float32 / float64 intervals
+ *                   refine_pair (1), reorder (1)  two cameras per round trip; most selective camera first
+ *                   emit_lanes (1), emit_busy (1: grids >= 64 M voxels, 2: always, 0: never)  record expansion form
+ *                   force_generic (0)  one thread per voxel everywhere (also env VOXCARVE_FORCE_GENERIC=1)
+ *   frame sets      grid_lds_kb (16), grid_min_shift (1)  LDS budget / finest block of the cropped block grids
+ *                                  (read by the next vc_upload_masks)
+ *   launch shape    hier_blocks_per_cu (48), emit_waves_per_cu (256), first_kv (1), first_blocks_per_cu (3),
+ *                   refine_b (8), refine_blocks_per_cu (8), fused_blocks_per_cu (8)
+ *   multi-GPU       gather_compact (1)  exchange occupancy words instead of records;
+ *                   gather_sync (1)  0: vc_allgather returns once its work is queued
+ * Unknown names or out-of-range values return VC_ERR_ARG. */
 int vc_set_option(vc_ctx *ctx, const char *name, int value);
 int vc_timing(vc_ctx *ctx, vc_timing_t *out);
 int vc_timing_reset(vc_ctx *ctx);
