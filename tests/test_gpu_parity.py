@@ -622,8 +622,13 @@ def _run_bench(args, nproc=1, timeout=300):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable]
     if nproc > 1:
+        import socket
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
         cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
-                "--master-port", "29577"]
+                "--master-port", str(port)]
     cmd += [os.path.join(root, "bench.py"), "--gpus", str(nproc)] + args
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
