@@ -530,7 +530,7 @@ __device__ __forceinline__ void lut_refine_body(const CarveParams &p, uint32_t v
 }
 
 template <int B, bool HIER, bool PAIR, bool TILE = false>
-__global__ __launch_bounds__(kBlock) void k_lut_refine(const CarveParams p)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_lut_refine(const CarveParams p)
 {
     extern __shared__ uint32_t s_grid[];                          // HIER: the cropped block grids of all cameras
     lut_refine_body<B, HIER, PAIR, TILE>(p, blockIdx.x, gridDim.x, s_grid);
@@ -748,7 +748,7 @@ __device__ __forceinline__ uint64_t segment_box_f32(const CamDev &c, double xa, 
 // rigid transform, 2: read from the boxes k_build_lut reduced once from the exact pixels (8 bytes per
 // word and camera, geometry only: they survive every new frame set; no table is built or read).
 template <bool TILE, int BOX>
-__global__ __launch_bounds__(kBlock) void k_carve_fused_hier(const CarveParams p)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_carve_fused_hier(const CarveParams p)
 {
     extern __shared__ uint32_t s_grid[];                          // the cropped block grids of all cameras
     {
