@@ -332,7 +332,8 @@ int build_block_grids(vc_ctx *ctx, Slot &s)
             const uint32_t blocks = 32u * g.cws * g.ch;
             maxblocks = blocks > maxblocks ? blocks : maxblocks;
         }
-        if ((size_t)total * sizeof(uint32_t) <= (size_t)ctx->grid_lds_kb * 1024) break;
+        // W <= 65535, H <= 32767: at 2^14-pixel blocks every grid is a few words, so the loop ends here at the latest
+        if ((size_t)total * sizeof(uint32_t) <= (size_t)ctx->grid_lds_kb * 1024 || s.gshift == 14) break;
     }
     s.grid_words = total;
     VC_TRY(ensure(ctx, s.grid, (size_t)total + 4));               // + padding: kernels copy it 16 bytes at a time
