@@ -557,6 +557,14 @@ def test_full_size_1024_properties(eng, cams, masks, frames):
         sel = (idx >= i0) & (idx < i1)
         assert np.array_equal(idx[sel], want["idx"])
         assert np.array_equal(rec[sel].view(np.uint8).reshape(-1, 8)[:, 4:7][:, ::-1], want["bgr"])
+    # with enough host cores (the GPU box has 256) the C oracle carves the WHOLE 1024^3 grid in seconds: every
+    # one of the ~30 M records, index and colour, against both device modes
+    if len(os.sched_getaffinity(0)) >= 32:
+        want = carve_c.carve(*grid, fx.oracle_cams(cams), masks, frames, cap=1 << 26)
+        assert want["count"] == n and np.array_equal(idx, want["idx"])
+        assert np.array_equal(rec.view(np.uint8).reshape(-1, 8)[:, 4:7][:, ::-1], want["bgr"])
+        assert np.all(rec.view(np.uint8).reshape(-1, 8)[:, 7] == 1)
+        del want
     # 8-way slab split (BASELINE config 4) concatenates to the same list -- as records, and in the compact
     # form the ranks exchange (non-zero occupancy words, expanded on one device; uneven work-balanced bounds)
     parts, ents = [], []
@@ -574,7 +582,7 @@ def test_full_size_1024_properties(eng, cams, masks, frames):
     assert allent.shape[0] * 16 * 10 < rec.size * 8                     # > 10x fewer bytes than the records
     assert eng.expand_entries(allent) == n
     assert hashlib.sha256(eng.fetch_gathered().tobytes()).hexdigest() == digest
-    # LUT mode on one slab (the table for the whole grid is 17 GB; a quarter is plenty here)
+    # LUT mode on one slab, then on the whole grid (34 GB of tables: the bench configuration itself)
     eng.set_slab(256, 512)
     eng.build_lut()
     a = eng.carve(mode="lut")
@@ -583,6 +591,15 @@ def test_full_size_1024_properties(eng, cams, masks, frames):
     i0 = 256 * 1024 * 1024
     sel = (idx >= i0) & (idx < 2 * i0)
     assert np.array_equal(ra, rec[sel])
+    del ra, sel
+    eng.set_slab(0, 1024)
+    eng.build_lut()
+    assert eng.carve(mode="lut") == n
+    assert hashlib.sha256(eng.fetch_records().tobytes()).hexdigest() == digest
+    eng.set_option("lut_hier", 0)                                       # the streaming form of the same table
+    assert eng.carve(mode="lut") == n
+    assert hashlib.sha256(eng.fetch_records().tobytes()).hexdigest() == digest
+    eng.set_option("lut_hier", 1)
 
 
 def test_index_width_at_the_u32_limit(eng, cams, masks, frames):
