@@ -14,7 +14,7 @@
 //                   k_lut_first + k_lut_refine<.,false,.>   the table streamed without skipping (roofline_stream)
 //                   k_carve_fused<KSUB,NY64>, k_carve_generic<LUT,VM>   chunked / one thread per voxel (any shape,
 //                                                                     thresholds below C, camera bit masks)
-//   compaction      k_count_groups, k_scan_groups, k_scan_blocks, k_busy_list, k_emit_busy / k_emit_lanes / k_emit_words
+//   compaction      k_count_groups, k_scan_groups, k_scan_blocks | k_finish_scan, k_emit_busy / k_emit_lanes / k_emit_words
 //   multi-GPU       k_count_nz, k_pack_entries, k_count_entries, k_emit_lanes<.,INDIRECT>, k_zero_dead_groups
 //
 // Cameras are visited most-selective first (order[]); every level stops as soon as nothing it covers can
@@ -1128,7 +1128,7 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_groups(const uint32_t *__re
     const uint32_t i = blockIdx.x * kScanBlock + t;
     const uint32_t c = (i < ngroups) ? cnt[i] : 0u;      // <= 4096 each: a block total fits u32
     const uint32_t incl = wave_inclusive_scan(c, lane);
-    // busyoff != null: the same scan over "group has survivors", for the list of busy groups (k_busy_list)
+    // busyoff != null: the same scan over "group has survivors", for the list of busy groups (k_finish_scan)
     const uint32_t f = (busyoff && c) ? 1u : 0u;
     const uint32_t fincl = busyoff ? wave_inclusive_scan(f, lane) : 0u;
     if (lane == 63) { wsum[wave] = incl; wbusy[wave] = fincl; }
@@ -1151,18 +1151,16 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_groups(const uint32_t *__re
             blockoff[0] = 0;
             blockoff[1] = total;
             *total_host = total;
-            if (busyoff) { busyblock[0] = 0; busyblock[1] = ftotal; }
+            if (busyoff) busyblock[0] = ftotal;                  // single block: this is the count of busy groups
         }
     }
 }
 
 // Level 2: exclusive scan of the (at most kScanBlock) block sums; blockoff[nblocks] = total.
 __global__ __launch_bounds__(kScanBlock) void k_scan_blocks(const uint64_t *__restrict__ blocksum, uint32_t nblocks,
-                                                            uint64_t *__restrict__ blockoff, uint64_t *__restrict__ total_host,
-                                                            const uint32_t *__restrict__ busysum, uint32_t *__restrict__ busyblock)
+                                                            uint64_t *__restrict__ blockoff, uint64_t *__restrict__ total_host)
 {
     __shared__ uint64_t wsum[kScanBlock / 64];
-    __shared__ uint32_t wbusy[kScanBlock / 64];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const uint64_t c = (t < nblocks) ? blocksum[t] : 0ull;
     uint64_t incl = c;
@@ -1171,37 +1169,81 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_blocks(const uint64_t *__re
         const uint64_t o = __shfl_up(incl, d);
         if (lane >= (uint32_t)d) incl += o;
     }
-    const uint32_t f = (busysum && t < nblocks) ? busysum[t] : 0u;     // busy groups of the block: <= 1024
-    const uint32_t fincl = busysum ? wave_inclusive_scan(f, lane) : 0u;
-    if (lane == 63) { wsum[wave] = incl; wbusy[wave] = fincl; }
+    if (lane == 63) wsum[wave] = incl;
     __syncthreads();
     uint64_t before = 0, total = 0;
-    uint32_t fbefore = 0, ftotal = 0;
 #pragma unroll
     for (uint32_t k = 0; k < kScanBlock / 64; ++k) {
         const uint64_t s = wsum[k];
-        const uint32_t fs = wbusy[k];
-        if (k < wave) { before += s; fbefore += fs; }
-        total += s; ftotal += fs;
+        if (k < wave) before += s;
+        total += s;
     }
-    if (t < nblocks) {
-        blockoff[t] = before + incl - c;
-        if (busysum) busyblock[t] = fbefore + fincl - f;
+    if (t < nblocks) blockoff[t] = before + incl - c;
+    if (t == 0) {
+        blockoff[nblocks] = total;
+        *total_host = total;
+    }
+}
+
+// Level 2 of both scans and the list of busy groups in one launch (grids large enough for the list: see
+// kBusyListMinGroups).  A workgroup covers 256 consecutive groups, all inside one scan block b, so all it needs
+// of the busy scan is the sum of the blocks before b; workgroup 0 also does the whole level-2 scan of the
+// survivor sums (at most 1024 values, four per thread) that the expansion reads through blockoff.
+__global__ __launch_bounds__(kBlock) void k_finish_scan(const uint64_t *__restrict__ blocksum, uint32_t nblocks,
+                                                        uint64_t *__restrict__ blockoff, uint64_t *__restrict__ total_host,
+                                                        const uint32_t *__restrict__ busysum, uint32_t *__restrict__ busycount,
+                                                        const uint32_t *__restrict__ cnt, uint32_t ngroups,
+                                                        const uint32_t *__restrict__ busyoff, uint32_t *__restrict__ list)
+{
+    __shared__ uint32_t wred[kBlock / 64];
+    __shared__ uint64_t wsum[kBlock / 64];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint32_t i = blockIdx.x * kBlock + t;
+    const uint32_t b = (blockIdx.x * kBlock) / kScanBlock;            // scan block of this workgroup's groups
+    // busy groups in the scan blocks before b (for workgroup 0 too: it reports the total)
+    uint32_t part = 0, all = 0;
+    for (uint32_t k = t; k < nblocks; k += kBlock) {
+        const uint32_t v = busysum[k];
+        if (k < b) part += v;
+        all += v;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { part += __shfl_xor(part, d); all += __shfl_xor(all, d); }
+    if (lane == 0) wred[wave] = part;
+    __syncthreads();
+    const uint32_t before = wred[0] + wred[1] + wred[2] + wred[3];
+    if (i < ngroups && cnt[i]) list[before + busyoff[i]] = i;
+    if (blockIdx.x != 0) return;
+    __syncthreads();
+    if (lane == 0) wred[wave] = all;
+    // level 2 of the survivor scan: thread t owns blocks 4t .. 4t+3
+    uint64_t v[4], own = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] = (4 * t + k < nblocks) ? blocksum[4 * t + k] : 0ull; own += v[k]; }
+    uint64_t incl = own;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t o = __shfl_up(incl, d);
+        if (lane >= (uint32_t)d) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint64_t base = incl - own, total = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kBlock / 64; ++k) {
+        if (k < wave) base += wsum[k];
+        total += wsum[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (4 * t + k < nblocks) blockoff[4 * t + k] = base;
+        base += v[k];
     }
     if (t == 0) {
         blockoff[nblocks] = total;
         *total_host = total;
-        if (busysum) busyblock[nblocks] = ftotal;
+        *busycount = wred[0] + wred[1] + wred[2] + wred[3];
     }
-}
-
-// The groups that have survivors, ascending: what the record expansion iterates over (5 of 6 groups have none).
-__global__ __launch_bounds__(kBlock) void k_busy_list(const uint32_t *__restrict__ cnt, uint32_t ngroups,
-                                                      const uint32_t *__restrict__ busyoff, const uint32_t *__restrict__ busyblock,
-                                                      uint32_t *__restrict__ list)
-{
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i < ngroups && cnt[i]) list[busyblock[i / kScanBlock] + busyoff[i]] = i;
 }
 
 // BGR bytes -> one BGRX dword per pixel, so a colour sample is a single aligned load.
@@ -1394,7 +1436,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_lanes(const EmitParams p)
     emit_group_lanes<FROM_LUT, ALLSEEN, EB, INDIRECT>(p, g, lane);
 }
 
-// The same expansion driven by the list of busy groups (k_busy_list): a fixed grid of waves strides over
+// The same expansion driven by the list of busy groups (k_finish_scan): a fixed grid of waves strides over
 // it, so no wave is launched only to find its group empty (5 of 6 are).
 template <bool FROM_LUT, bool ALLSEEN, int EB>
 __global__ __launch_bounds__(kBlock) void k_emit_busy(const EmitParams p)

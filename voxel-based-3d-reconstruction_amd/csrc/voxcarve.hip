@@ -410,8 +410,7 @@ int scan_counts(vc_ctx *ctx, const uint32_t *cnt, uint32_t ngroups, uint32_t *of
                        (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
     VC_HIP(ctx, hipGetLastError());
     if (nscan > 1) {
-        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(kScanBlock), 0, ctx->stream, bsum, nscan, boff, total_host,
-                           (const uint32_t *)nullptr, (uint32_t *)nullptr);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(kScanBlock), 0, ctx->stream, bsum, nscan, boff, total_host);
         VC_HIP(ctx, hipGetLastError());
     }
     return VC_OK;
@@ -1090,20 +1089,19 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
         VC_TRY(ensure(ctx, sb.busyoff, ngroups));
         VC_TRY(ensure(ctx, sb.busylist, ngroups));
         VC_TRY(ensure(ctx, sb.busysum, kMaxScanBlocks));
-        VC_TRY(ensure(ctx, sb.busyblock, kMaxScanBlocks + 1));
+        VC_TRY(ensure(ctx, sb.busyblock, 1));                    // the count of busy groups
     }
     hipLaunchKernelGGL(k_scan_groups, dim3(nscan), dim3(kScanBlock), 0, s2, sb.groupcnt.ptr, ngroups, sb.groupoff.ptr,
                        sb.blocksum.ptr, sb.blockoff.ptr, sb.h_total, sb.busy ? sb.busyoff.ptr : nullptr, sb.busysum.ptr,
                        sb.busyblock.ptr);
     VC_HIP(ctx, hipGetLastError());
-    if (nscan > 1) {
-        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(kScanBlock), 0, s2, sb.blocksum.ptr, nscan, sb.blockoff.ptr, sb.h_total,
-                           sb.busy ? (const uint32_t *)sb.busysum.ptr : nullptr, sb.busyblock.ptr);
-        VC_HIP(ctx, hipGetLastError());
-    }
     if (sb.busy) {
-        hipLaunchKernelGGL(k_busy_list, dim3(grid_for(ngroups)), block, 0, s2, sb.groupcnt.ptr, ngroups, sb.busyoff.ptr,
-                           sb.busyblock.ptr, sb.busylist.ptr);
+        // level 2 of both scans + the list in one launch (k_scan_groups has left the count in busyblock[0] when nscan == 1)
+        hipLaunchKernelGGL(k_finish_scan, dim3(grid_for(ngroups)), block, 0, s2, sb.blocksum.ptr, nscan, sb.blockoff.ptr, sb.h_total,
+                           sb.busysum.ptr, sb.busyblock.ptr, sb.groupcnt.ptr, ngroups, sb.busyoff.ptr, sb.busylist.ptr);
+        VC_HIP(ctx, hipGetLastError());
+    } else if (nscan > 1) {
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(kScanBlock), 0, s2, sb.blocksum.ptr, nscan, sb.blockoff.ptr, sb.h_total);
         VC_HIP(ctx, hipGetLastError());
     }
 
@@ -1123,7 +1121,7 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     }
     e.records = sb.records.ptr;
     e.capacity = sb.records.cap;
-    e.busylist = sb.busylist.ptr; e.busycount = sb.busyblock.ptr ? sb.busyblock.ptr + nscan : nullptr;
+    e.busylist = sb.busylist.ptr; e.busycount = sb.busyblock.ptr;
     if (!sb.no_records) VC_TRY(launch_emit(ctx, sb, s2));
     if (auto_exchange) {
         VC_TRY(enqueue_pack(ctx, sb));
