@@ -149,6 +149,8 @@ int vc_fetch_occupancy(vc_ctx *ctx, uint8_t *bits);
  *                   lut_tile, fused_tile (1)  words of 4 x-rows x 16 y where nx % 4 == 0 and ny % 64 == 0
  *                   fused_hier (1), fused_boxes (1), fused_f32box (1)  table-free kernel: word rejection; boxes read /
  *                                  bounded on the fly in float32 / float64 intervals
+ *                   fused_color_table (0)  table-free carve, survivors coloured from the colour camera's table (4 B per
+ *                                  voxel of the whole grid, one camera) instead of by projecting each of them again
  *                   refine_pair (1), reorder (1)  two cameras per round trip; most selective camera first
  *                   emit_lanes (1), emit_busy (1: grids >= 64 M voxels, 2: always, 0: never)  record expansion form
  *                   force_generic (0)  one thread per voxel everywhere (also env VOXCARVE_FORCE_GENERIC=1)

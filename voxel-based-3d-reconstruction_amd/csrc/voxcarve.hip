@@ -178,6 +178,7 @@ struct vc_ctx {
     int lut_tile = 1;                // hierarchical LUT kernel on tile words (needs nx % 4 == 0, ny % 64 == 0)
     int fused_tile = 1;              // the same word shape for the hierarchical table-free kernel
     int fused_f32box = 1;            // its word boxes from float32 intervals after a float64 rigid transform ...
+    int fused_color_table = 0;       // VC_MODE_FUSED: colour the survivors from the colour camera's table (one camera, whole grid)
     int fused_boxes = 1;             // ... or read from boxes reduced once from the exact pixels (no table involved)
     DevBuf<uint32_t> d_mbbox;        // per camera foreground pixel bounding box (k_mask_bbox)
     uint32_t *h_mbbox = nullptr;     // pinned, 4 per camera
@@ -1118,6 +1119,12 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
         if (s.frames.ptr && s.have_frame[color_cam])
             e.frame = s.frames.ptr + (size_t)color_cam * ctx->H * ctx->W;
         if (mode == VC_MODE_LUT) e.lut = ctx->d_lut.ptr + (size_t)color_cam * p.n_pad;
+        else if (ctx->fused_color_table && !sb.no_records) {
+            // table-free carve, but the colour look-up of the survivors reads the colour camera's table (4 B per
+            // voxel of the whole grid, one camera) instead of projecting every survivor again
+            VC_TRY(ensure_color_table(ctx, color_cam));
+            e.lut = ctx->d_lut_color.ptr + ctx->i0();
+        }
     }
     e.records = sb.records.ptr;
     e.capacity = sb.records.cap;
@@ -1287,6 +1294,7 @@ int vc_set_option(vc_ctx *ctx, const char *name, int value)
     else if (k == "fused_tile") ctx->fused_tile = value != 0;
     else if (k == "fused_f32box") ctx->fused_f32box = value != 0;
     else if (k == "fused_boxes") ctx->fused_boxes = value != 0;
+    else if (k == "fused_color_table") ctx->fused_color_table = value != 0;
     else if (k == "gather_compact") ctx->gather_compact = value != 0;
     else if (k == "gather_sync") ctx->gather_sync = value != 0;
     else if (k == "refine_pair") ctx->refine_pair = value != 0;
