@@ -229,6 +229,17 @@ def test_hostile_cameras_inside_the_volume(eng, seed):
             assert eng.carve(mode=mode, color_cam=0) == want["count"], (mode, c)
             idx, rgb, _ = eng.fetch()
             assert np.array_equal(idx, want["idx"]) and np.array_equal(rgb[:, ::-1], want["bgr"]), (mode, c)
+        # the table-free kernel bounding its words on the fly: float32 intervals, then float64 intervals
+        try:
+            for opts in ({"fused_boxes": 0, "fused_f32box": 1}, {"fused_boxes": 0, "fused_f32box": 0}):
+                for k, v in opts.items():
+                    eng.set_option(k, v)
+                assert eng.carve(mode="fused", color_cam=0) == want["count"], (opts, c)
+                idx, rgb, _ = eng.fetch()
+                assert np.array_equal(idx, want["idx"]) and np.array_equal(rgb[:, ::-1], want["bgr"]), (opts, c)
+        finally:
+            eng.set_option("fused_boxes", 1)
+            eng.set_option("fused_f32box", 1)
     assert total > 500
 
 
