@@ -296,6 +296,46 @@ def test_device_mask_postfilter_matches_restatement(eng, cams, masks):
         assert np.array_equal(eng.fetch_mask(c), np.where(noisy[c] > 0, 255, 0))
 
 
+def test_cropped_block_grid_edge_cases(eng, cams, masks, frames):
+    """The block grids keep only the blocks around each camera's foreground (word-aligned columns, block rows):
+    foreground confined to a corner pixel, the last row / column, one pixel wide lines, two far-apart blobs,
+    a blob straddling a 32-block word boundary -- one camera at a time so that the word-rejecting kernels run
+    (min_views == C) and leave survivors to compare."""
+    from oracle import carve_c
+    H, W = masks[0].shape
+    variants = []
+    m = np.zeros((H, W), np.uint8); m[0, 0] = 255; variants.append(("corner pixel", m))
+    m = np.zeros((H, W), np.uint8); m[H - 1, W - 1] = 255; variants.append(("last pixel", m))
+    m = np.zeros((H, W), np.uint8); m[H - 1, :] = 255; variants.append(("last row", m))
+    m = np.zeros((H, W), np.uint8); m[:, W - 1] = 255; variants.append(("last column", m))
+    m = np.zeros((H, W), np.uint8); m[H // 2, :] = 255; variants.append(("one row", m))
+    m = np.zeros((H, W), np.uint8); m[:, 300] = 255; variants.append(("one column", m))
+    m = np.zeros((H, W), np.uint8); m[5:9, 3:7] = 255; m[400:430, 600:640] = 255; variants.append(("two blobs", m))
+    m = np.zeros((H, W), np.uint8); m[200:260, 50:80] = 255; variants.append(("across the first word boundary at 2 px blocks", m))
+    m = np.zeros((H, W), np.uint8); m[100:300, 120:135] = 255; variants.append(("across a word boundary at 4 px blocks", m))
+    m = np.zeros((H, W), np.uint8); variants.append(("empty", m))
+    grid = (64, 64, 64)
+    eng.set_grid(*grid)
+    seen_nonempty = 0
+    for c in (0, 2):
+        eng.set_cameras([cams[c]], H, W)
+        oc = fx.oracle_cams([cams[c]])
+        for shift in (1, 2, 3):
+            eng.set_option("grid_min_shift", shift)
+            for label, m in variants:
+                eng.upload_masks([m])
+                eng.upload_frame(0, frames[c])
+                eng.build_lut()
+                want = carve_c.carve(*grid, oc, [m], [frames[c]], color_cam=0)
+                seen_nonempty += want["count"] > 0
+                for mode in ("lut", "fused"):
+                    assert eng.carve(mode=mode, color_cam=0) == want["count"], (label, c, shift, mode)
+                    idx, rgb, _ = eng.fetch()
+                    assert np.array_equal(idx, want["idx"]) and np.array_equal(rgb[:, ::-1], want["bgr"]), (label, c, shift, mode)
+    eng.set_option("grid_min_shift", 1)
+    assert seen_nonempty > 20
+
+
 def test_all_background_and_all_foreground(eng, cams, masks):
     from oracle import carve_c
     H, W = masks[0].shape
