@@ -734,3 +734,47 @@ def test_bench_two_ranks_host_transport(built):
     assert d["config"]["survivors"] == 461113
     for m in d["other_modes"].values():
         assert m["survivors"] == 461113
+
+
+def test_property_random_shapes_cameras_masks(eng):
+    """Property test (hypothesis, derandomised): for drawn grid shapes (tile-eligible or not), camera counts, mask
+    sizes, foreground structure (noise / one blob / empty / full) and thresholds, both device modes give the
+    oracle's records -- index, order, colour, seen flag."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    from oracle import carve_c
+
+    @settings(max_examples=40, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(seed=st.integers(0, 10 ** 6), nx=st.integers(1, 6), ny=st.sampled_from([1, 7, 16, 63, 64, 65, 128, 192, 200]),
+           nz=st.integers(1, 9), C=st.integers(1, 5), H=st.integers(8, 70), W=st.integers(8, 90),
+           kind=st.sampled_from(["noise", "blob", "empty", "full", "sparse"]), below=st.booleans(), quad=st.booleans())
+    def check(seed, nx, ny, nz, C, H, W, kind, below, quad):
+        nxx = nx * 4 if quad else nx                       # quad: nx % 4 == 0, so ny % 64 == 0 shapes take the tile kernels
+        cams3, masks3, frames3 = fx.random_scene(seed, C=C, H=H, W=W, fg=0.5)
+        rng = np.random.default_rng(seed)
+        for m in masks3:
+            if kind == "blob":
+                m[:] = 0
+                y0, x0 = int(rng.integers(0, H)), int(rng.integers(0, W))
+                m[y0:y0 + int(rng.integers(1, H)), x0:x0 + int(rng.integers(1, W))] = 255
+            elif kind == "empty":
+                m[:] = 0
+            elif kind == "full":
+                m[:] = 7
+            elif kind == "sparse":
+                m[rng.random((H, W)) < 0.9] = 0
+        mv = max(1, C - 1) if below else C
+        cc = int(rng.integers(0, C))
+        want = carve_c.carve(nxx, ny, nz, fx.oracle_cams(cams3), masks3, frames3, min_views=mv, color_cam=cc, want_viewmask=True)
+        seen_want = ((want["viewmask"][want["idx"]] >> cc) & 1).astype(bool)
+        eng.set_grid(nxx, ny, nz)
+        eng.set_cameras(cams3, H, W)
+        eng.upload_masks(masks3)
+        eng.upload_frame(cc, frames3[cc])
+        eng.build_lut()
+        for mode in ("lut", "fused"):
+            assert eng.carve(mode=mode, min_views=mv, color_cam=cc) == want["count"], (mode,)
+            idx, rgb, seen = eng.fetch()
+            assert np.array_equal(idx, want["idx"]) and np.array_equal(seen, seen_want), (mode,)
+            assert np.array_equal(rgb[:, ::-1], want["bgr"]), (mode,)
+
+    check()
