@@ -145,6 +145,8 @@ struct StepBuf {
 struct vc_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // scan + record expansion of step i, beside the carve of step i+1 on `stream`
+    int overlap = 1;                 // (one stream when a communicator is attached: its collectives order everything)
     StepBuf sb[2];
     int head = 0, npending = 0, cur = -1;    // next set to issue into, steps in flight, set holding the fetched result
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -608,6 +610,7 @@ int vc_create(int device, vc_ctx **out)
     ctx->device = device;
     memset(&ctx->tm, 0, sizeof ctx->tm);
     hipError_t e1 = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e1 == hipSuccess) e1 = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
     for (int k = 0; k < 2 && e1 == hipSuccess; ++k) {
         StepBuf &b = ctx->sb[k];
         e1 = hipEventCreate(&b.e0);
@@ -635,6 +638,7 @@ int vc_destroy(vc_ctx *ctx)
     if (!ctx) return VC_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
     for (Slot &s : ctx->slots) { release(s.bits); release(s.frames); release(s.grid); }
     release(ctx->d_axes); release(ctx->d_stage); release(ctx->d_morph); release(ctx->d_lut); release(ctx->d_bbox); release(ctx->d_lut_tile); release(ctx->d_tbox);
@@ -659,6 +663,7 @@ int vc_destroy(vc_ctx *ctx)
     if (ctx->h_mbbox) (void)hipHostFree(ctx->h_mbbox);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
     for (int i = 0; i < 4; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return VC_OK;
@@ -670,6 +675,7 @@ int vc_synchronize(vc_ctx *ctx)
 {
     if (!ctx) return VC_ERR_ARG;
     VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    VC_HIP(ctx, hipStreamSynchronize(ctx->stream2));
     return finish_gather(ctx);
 }
 
@@ -756,6 +762,7 @@ int vc_upload_masks(vc_ctx *ctx, uint32_t slot, const uint8_t *masks)
     Slot *s = nullptr;
     VC_TRY(slot_at(ctx, slot, &s));
     VC_HIP(ctx, hipSetDevice(ctx->device));
+    VC_HIP(ctx, hipStreamSynchronize(ctx->stream2));      // an expansion in flight may still read this slot's mask bits
     const size_t HW = (size_t)ctx->H * ctx->W;
     VC_TRY(ensure(ctx, ctx->d_stage, HW * (ctx->C > 3 ? ctx->C : 3) + 64));
     VC_TRY(ensure(ctx, s->bits, (size_t)ctx->mwords * ctx->C));
@@ -822,6 +829,7 @@ int vc_upload_frame(vc_ctx *ctx, uint32_t slot, uint32_t cam, const uint8_t *bgr
     VC_TRY(slot_at(ctx, slot, &s));
     if (cam >= ctx->C) return fail(ctx, VC_ERR_ARG, "camera %u not in [0,%u)", cam, ctx->C);
     VC_HIP(ctx, hipSetDevice(ctx->device));
+    VC_HIP(ctx, hipStreamSynchronize(ctx->stream2));      // an expansion in flight may still read this slot's frame
     const size_t npix = (size_t)ctx->H * ctx->W;
     VC_TRY(ensure(ctx, s->frames, npix * ctx->C));
     VC_TRY(ensure(ctx, ctx->d_stage, npix * (ctx->C > 3 ? ctx->C : 3) + 64));
@@ -1076,7 +1084,10 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     VC_HIP(ctx, hipEventRecord(sb.e1, ctx->stream));
 
     // ---- compaction: group counts -> two-level scan -> record expansion
-    hipStream_t s2 = ctx->stream;
+    // the carve kernels are VALU-issue bound, the expansion is memory bound: on its own stream the expansion of this
+    // step runs beside the carve of the next one (two steps in flight) instead of after it
+    hipStream_t s2 = (ctx->overlap && !ctx->comm) ? ctx->stream2 : ctx->stream;
+    if (s2 != ctx->stream) VC_HIP(ctx, hipStreamWaitEvent(s2, sb.e1, 0));
     // kernels that do not know their group totals (fused, generic) get them counted
     const bool counted = fast && (mode == VC_MODE_LUT || (ctx->ny % 64 == 0 && ctx->fused_hier));
     if (!counted) {
@@ -1286,6 +1297,7 @@ int vc_set_option(vc_ctx *ctx, const char *name, int value)
     else if (k == "lut_hier") ctx->lut_hier = value != 0;
     else if (k == "fused_hier") ctx->fused_hier = value != 0;
     else if (k == "emit_lanes") ctx->emit_lanes = value != 0;
+    else if (k == "overlap") ctx->overlap = value != 0;
     else if (k == "emit_busy" && value >= 0 && value <= 2) ctx->emit_busy = value;          // 0 never, 1 large grids, 2 always
     else if (k == "emit_waves_per_cu" && value >= 4 && value <= 1024) ctx->emit_waves_per_cu = value;
     else if (k == "lut_tile") ctx->lut_tile = value != 0;
