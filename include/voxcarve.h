@@ -158,6 +158,8 @@ int vc_fetch_occupancy(vc_ctx *ctx, uint8_t *bits);
  *                                  (read by the next vc_upload_masks)
  *   launch shape    hier_blocks_per_cu (48), emit_waves_per_cu (256), first_kv (1), first_blocks_per_cu (3),
  *                   refine_b (8), refine_blocks_per_cu (8), fused_blocks_per_cu (8)
+ *   streams         overlap (1)  scan + record expansion of a step on a second stream, beside the next step's carve
+ *                                  (single stream while a communicator is attached)
  *   multi-GPU       gather_compact (1)  exchange occupancy words instead of records;
  *                   gather_sync (1)  0: vc_allgather returns once its work is queued
  * Unknown names or out-of-range values return VC_ERR_ARG. */
