@@ -127,9 +127,12 @@ class Group:
             self.shm.close()
 
 
-def run_mode(eng, grp, mode, steps, warmup, multi, host_transport=None, depth=2, exchange="compact"):
-    """W untimed + K timed steps of one mode; returns (seconds, kernel ms avg, survivors, total)."""
+def run_mode(eng, grp, mode, steps, warmup, multi, host_transport=None, depth=2, exchange="compact", overlap=1):
+    """W untimed + K timed steps of one mode; returns (seconds, kernel ms avg, survivors, total).
+    overlap: the scan + record expansion of a step on a second stream, beside the next step's carve (the product's
+    default).  lut_stream exists to measure ONE kernel against the HBM roof, so it always runs on one stream."""
     eng.set_option("lut_hier", 0 if mode == "lut_stream" else 1)
+    eng.set_option("overlap", 0 if mode == "lut_stream" else overlap)
     mode = "lut" if mode == "lut_stream" else mode
 
     def finish():
@@ -276,6 +279,12 @@ def main():
                          "compact_ms": tm["compact_ms"], "gather_ms": tm["gather_ms_sum"] / max(1, tm["gathers"]),
                          "exchange_ms": tm["exchange_ms"], "tm": tm}
 
+    # the dominant kernel of the headline mode without a neighbour: the same steps on one stream (short, untimed for `value`)
+    if not multi:                       # (a rank of a communicator runs on one stream anyway)
+        alone = run_mode(eng, grp, args.mode, max(10, args.steps // 5), 2, multi, host_transport, args.depth, args.exchange, overlap=0)
+        results[args.mode]["kernel_ms_alone"] = alone[1]
+        results[args.mode]["ms_per_step_one_stream"] = alone[0] / max(10, args.steps // 5) * 1e3
+        eng.set_option("overlap", 1)
     n_local_vox = eng.n_voxels
     total_vv = float(G) ** 3 * C
     head = results[args.mode]
@@ -320,6 +329,12 @@ def main():
                 "note": "52 f64 flop per voxel-view counted for ALL voxel-views; most 64-voxel words are decided "
                         "from the pixel box of the word (8 B per word and camera, reduced once per camera set) and never "
                         "projected voxel by voxel"}
+    if not multi:
+        roof["concurrency"] = ("two steps in flight on two streams: the record expansion of the previous step runs beside this "
+                               "kernel, which stretches its launches (avg_launch_ms, as rocprofv3 sees them too) while the step "
+                               "gets shorter; on one stream the kernel takes avg_launch_ms_alone and the step ms_per_step_one_stream")
+        roof["avg_launch_ms_alone"] = round(head["kernel_ms_alone"], 4)
+        roof["ms_per_step_one_stream"] = round(head["ms_per_step_one_stream"], 4)
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
     roof_stream = stream_roofline(results["lut_stream"]) if args.mode != "lut_stream" else None
     if os.path.exists(traffic_file):
