@@ -221,8 +221,10 @@ struct vc_ctx {
     bool gather_pending = false;     // a queued all-gather whose completion has not been observed yet
     uint64_t gather_expect = 0;
     DevBuf<uint64_t> d_ent_all;              // all ranks' pairs in rank order
-    DevBuf<uint32_t> d_xcnt, d_xoff;         // scan scratch of the pack and expand passes (stream-ordered)
+    DevBuf<uint32_t> d_xcnt, d_xoff;         // scan scratch of the pack pass ...
     DevBuf<uint64_t> d_xbsum, d_xboff;
+    DevBuf<uint32_t> d_ycnt, d_yoff;         // ... and of the expansion, which may run on the second stream beside a pack
+    DevBuf<uint64_t> d_ybsum, d_yboff;
     uint64_t *h_xtotal = nullptr;            // pinned
     uint64_t packed_entries = 0;
     bool packed = false;
@@ -405,15 +407,15 @@ constexpr size_t kMaxFirstLds = 64 * 1024; // static limit of one workgroup's dy
 constexpr uint32_t kEstimateSamples = 1u << 16;
 
 // counts -> exclusive offsets (two levels) on the context's stream; the total also lands in *total_host
-int scan_counts(vc_ctx *ctx, const uint32_t *cnt, uint32_t ngroups, uint32_t *off, uint64_t *bsum, uint64_t *boff,
+int scan_counts(vc_ctx *ctx, hipStream_t st, const uint32_t *cnt, uint32_t ngroups, uint32_t *off, uint64_t *bsum, uint64_t *boff,
                 uint64_t *total_host)
 {
     const uint32_t nscan = (ngroups + kScanBlock - 1) / kScanBlock;
-    hipLaunchKernelGGL(k_scan_groups, dim3(nscan), dim3(kScanBlock), 0, ctx->stream, cnt, ngroups, off, bsum, boff, total_host,
+    hipLaunchKernelGGL(k_scan_groups, dim3(nscan), dim3(kScanBlock), 0, st, cnt, ngroups, off, bsum, boff, total_host,
                        (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
     VC_HIP(ctx, hipGetLastError());
     if (nscan > 1) {
-        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(kScanBlock), 0, ctx->stream, bsum, nscan, boff, total_host);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(kScanBlock), 0, st, bsum, nscan, boff, total_host);
         VC_HIP(ctx, hipGetLastError());
     }
     return VC_OK;
@@ -472,7 +474,7 @@ int enqueue_pack(vc_ctx *ctx, StepBuf &cur)
     hipLaunchKernelGGL(k_count_nz, grid, block, 0, ctx->stream, cur.words.ptr, nwords, ngroups, cur.groupcnt.ptr,
                        ctx->d_xcnt.ptr);
     VC_HIP(ctx, hipGetLastError());
-    VC_TRY(scan_counts(ctx, ctx->d_xcnt.ptr, ngroups, ctx->d_xoff.ptr, ctx->d_xbsum.ptr, ctx->d_xboff.ptr, ctx->h_xtotal));
+    VC_TRY(scan_counts(ctx, ctx->stream, ctx->d_xcnt.ptr, ngroups, ctx->d_xoff.ptr, ctx->d_xbsum.ptr, ctx->d_xboff.ptr, ctx->h_xtotal));
     hipLaunchKernelGGL(k_pack_entries, grid, block, 0, ctx->stream, cur.words.ptr, nwords, ngroups, cur.groupcnt.ptr, ctx->d_xoff.ptr,
                        ctx->d_xboff.ptr, nscan, ctx->i0(), cur.blockoff.ptr + nscan, cur.ent.ptr, cur.mine.ptr);
     VC_HIP(ctx, hipGetLastError());
@@ -530,19 +532,30 @@ int finish_gather(vc_ctx *ctx)
 // Expands M gathered entries (device, ascending) into the ordered survivor records of the whole grid
 // in ctx->d_gathered, coloured the way the current step was (its mode, colour camera and frame set).
 // S_hint = expected survivor count (0 = unknown: sized after a host synchronisation).
-int enqueue_expand(vc_ctx *ctx, const uint64_t *d_entries, uint64_t M, uint64_t S_hint)
+// st: the stream the expansion runs on (the second stream lets it run beside the next step's carve; its scan
+// scratch is its own because the next step's packing may be under way on the first).
+int enqueue_expand(vc_ctx *ctx, hipStream_t st, const uint64_t *d_entries, uint64_t M, uint64_t S_hint)
 {
     StepBuf &cur = ctx->sb[ctx->cur];
     *(ctx->h_xtotal + 1) = 0;
     if (M == 0) return VC_OK;
     const uint32_t ngroups = (uint32_t)((M + kGroupWords - 1) / kGroupWords);
-    VC_TRY(ensure_exchange_scratch(ctx, ngroups));
+    VC_TRY(ensure_exchange_scratch(ctx, 1));
+    VC_TRY(ensure(ctx, ctx->d_ycnt, ngroups));
+    VC_TRY(ensure(ctx, ctx->d_yoff, ngroups));
+    VC_TRY(ensure(ctx, ctx->d_ybsum, kMaxScanBlocks));
+    VC_TRY(ensure(ctx, ctx->d_yboff, kMaxScanBlocks + 1));
+    const bool from_lut = cur.mode == VC_MODE_LUT && cur.color_cam >= 0;
+    if (from_lut && !(ctx->lut_color_cam == cur.color_cam && ctx->d_lut_color.ptr)) {
+        VC_TRY(ensure_color_table(ctx, cur.color_cam));           // built on the first stream, once per camera
+        if (st != ctx->stream) VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     const dim3 grid((ngroups + 3) / 4), block(kBlock);
-    hipLaunchKernelGGL(k_count_entries, grid, block, 0, ctx->stream, d_entries, M, ngroups, ctx->d_xcnt.ptr);
+    hipLaunchKernelGGL(k_count_entries, grid, block, 0, st, d_entries, M, ngroups, ctx->d_ycnt.ptr);
     VC_HIP(ctx, hipGetLastError());
-    VC_TRY(scan_counts(ctx, ctx->d_xcnt.ptr, ngroups, ctx->d_xoff.ptr, ctx->d_xbsum.ptr, ctx->d_xboff.ptr, ctx->h_xtotal + 1));
+    VC_TRY(scan_counts(ctx, st, ctx->d_ycnt.ptr, ngroups, ctx->d_yoff.ptr, ctx->d_ybsum.ptr, ctx->d_yboff.ptr, ctx->h_xtotal + 1));
     if (S_hint == 0) {
-        VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        VC_HIP(ctx, hipStreamSynchronize(st));
         S_hint = *(ctx->h_xtotal + 1);
     }
     if (S_hint > ctx->d_gathered.cap)            // survivor counts drift from frame to frame: grow with slack
@@ -559,18 +572,14 @@ int enqueue_expand(vc_ctx *ctx, const uint64_t *d_entries, uint64_t M, uint64_t 
         if (s.frames.ptr && s.have_frame[cur.color_cam]) e.frame = s.frames.ptr + (size_t)cur.color_cam * ctx->H * ctx->W;
     }
     e.entries = d_entries;
-    e.groupcnt = ctx->d_xcnt.ptr; e.groupoff = ctx->d_xoff.ptr; e.blockoff = ctx->d_xboff.ptr;
+    e.groupcnt = ctx->d_ycnt.ptr; e.groupoff = ctx->d_yoff.ptr; e.blockoff = ctx->d_yboff.ptr;
     e.n = M * 64; e.i0 = 0; e.z0 = 0; e.ngroups = ngroups;
     e.records = ctx->d_gathered.ptr; e.capacity = ctx->d_gathered.cap;
-    const bool from_lut = cur.mode == VC_MODE_LUT && cur.color_cam >= 0;
-    if (from_lut) {
-        VC_TRY(ensure_color_table(ctx, cur.color_cam));
-        e.lut = ctx->d_lut_color.ptr;
-    } else e.lut = nullptr;
-    if (from_lut && cur.allseen) hipLaunchKernelGGL((k_emit_lanes<true, true, 8, true>), grid, block, 0, ctx->stream, e);
-    else if (from_lut) hipLaunchKernelGGL((k_emit_lanes<true, false, 8, true>), grid, block, 0, ctx->stream, e);
-    else if (cur.allseen) hipLaunchKernelGGL((k_emit_lanes<false, true, 4, true>), grid, block, 0, ctx->stream, e);
-    else hipLaunchKernelGGL((k_emit_lanes<false, false, 4, true>), grid, block, 0, ctx->stream, e);
+    e.lut = from_lut ? ctx->d_lut_color.ptr : nullptr;
+    if (from_lut && cur.allseen) hipLaunchKernelGGL((k_emit_lanes<true, true, 8, true>), grid, block, 0, st, e);
+    else if (from_lut) hipLaunchKernelGGL((k_emit_lanes<true, false, 8, true>), grid, block, 0, st, e);
+    else if (cur.allseen) hipLaunchKernelGGL((k_emit_lanes<false, true, 4, true>), grid, block, 0, st, e);
+    else hipLaunchKernelGGL((k_emit_lanes<false, false, 4, true>), grid, block, 0, st, e);
     VC_HIP(ctx, hipGetLastError());
     return VC_OK;
 }
@@ -656,6 +665,7 @@ int vc_destroy(vc_ctx *ctx)
     release(ctx->d_viewmask); release(ctx->d_scratch); release(ctx->d_counts); release(ctx->d_gathered);
     release(ctx->d_ent_all); release(ctx->d_xcnt); release(ctx->d_xoff); release(ctx->d_xbsum);
     release(ctx->d_xboff); release(ctx->d_lut_color);
+    release(ctx->d_ycnt); release(ctx->d_yoff); release(ctx->d_ybsum); release(ctx->d_yboff);
     if (ctx->h_xtotal) (void)hipHostFree(ctx->h_xtotal);
     if (ctx->h_total) (void)hipHostFree(ctx->h_total);
     if (ctx->h_est) (void)hipHostFree(ctx->h_est);
@@ -1378,6 +1388,7 @@ int vc_comm_destroy(vc_ctx *ctx)
     if (ctx->comm) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamSynchronize(ctx->stream2);
         ctx->gather_pending = false;
         VC_NCCL(ctx, g_rccl.CommDestroy(ctx->comm));
         ctx->comm = nullptr;
@@ -1422,7 +1433,7 @@ int vc_expand_entries(vc_ctx *ctx, const uint64_t *entries, uint64_t n_entries, 
     VC_TRY(ensure(ctx, ctx->d_ent_all, (size_t)(2 * n_entries)));
     if (n_entries)
         VC_HIP(ctx, hipMemcpyAsync(ctx->d_ent_all.ptr, entries, n_entries * 2 * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-    VC_TRY(enqueue_expand(ctx, ctx->d_ent_all.ptr, n_entries, 0));
+    VC_TRY(enqueue_expand(ctx, ctx->stream, ctx->d_ent_all.ptr, n_entries, 0));
     VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->gathered_total = n_entries ? *(ctx->h_xtotal + 1) : 0;
     ctx->gathered = true;
@@ -1464,8 +1475,11 @@ static int allgather_compact(vc_ctx *ctx, uint64_t *counts_out, uint64_t *total_
     }
     VC_NCCL(ctx, g_rccl.GroupEnd());
     VC_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
-    if (S) VC_TRY(enqueue_expand(ctx, ctx->d_ent_all.ptr, M, S));
-    VC_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    // the expansion runs beside the next step's carve (second stream) when the call does not wait for it anyway
+    hipStream_t xs = (ctx->overlap && !ctx->gather_sync) ? ctx->stream2 : ctx->stream;
+    if (xs != ctx->stream) VC_HIP(ctx, hipStreamWaitEvent(xs, ctx->ev[2], 0));
+    if (S) VC_TRY(enqueue_expand(ctx, xs, ctx->d_ent_all.ptr, M, S));
+    VC_HIP(ctx, hipEventRecord(ctx->ev[1], xs));
     ctx->gather_pending = true;
     ctx->gather_expect = S;
     if (counts_out) for (int r = 0; r < G; ++r) counts_out[r] = cur.h_counts[2 * r + 1];
