@@ -125,7 +125,7 @@ struct StepBuf {
     DevBuf<uint64_t> blocksum, blockoff;     // blockoff[nscan] = total
     DevBuf<uint64_t> records;
     uint64_t *h_total = nullptr;             // pinned
-    hipEvent_t e0 = nullptr, e_first = nullptr, e1 = nullptr, e2 = nullptr;
+    hipEvent_t e0 = nullptr, e_first = nullptr, e1 = nullptr, e2 = nullptr, e_scan = nullptr;
     bool pending = false, used = false;
     EmitParams emit;                         // kept for a re-run after a records regrow
     bool allseen = false, want_vm = false, has_first = false;
@@ -626,6 +626,7 @@ int vc_create(int device, vc_ctx **out)
         if (e1 == hipSuccess) e1 = hipEventCreate(&b.e_first);
         if (e1 == hipSuccess) e1 = hipEventCreate(&b.e1);
         if (e1 == hipSuccess) e1 = hipEventCreate(&b.e2);
+        if (e1 == hipSuccess) e1 = hipEventCreate(&b.e_scan);
         if (e1 == hipSuccess) e1 = hipHostMalloc(reinterpret_cast<void **>(&b.h_total), sizeof(uint64_t), hipHostMallocDefault);
     }
     for (int i = 0; i < 4 && e1 == hipSuccess; ++i) e1 = hipEventCreate(&ctx->ev[i]);
@@ -661,6 +662,7 @@ int vc_destroy(vc_ctx *ctx)
         if (b.e_first) (void)hipEventDestroy(b.e_first);
         if (b.e1) (void)hipEventDestroy(b.e1);
         if (b.e2) (void)hipEventDestroy(b.e2);
+        if (b.e_scan) (void)hipEventDestroy(b.e_scan);
     }
     release(ctx->d_viewmask); release(ctx->d_scratch); release(ctx->d_counts); release(ctx->d_gathered);
     release(ctx->d_ent_all); release(ctx->d_xcnt); release(ctx->d_xoff); release(ctx->d_xbsum);
@@ -1096,8 +1098,10 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     // ---- compaction: group counts -> two-level scan -> record expansion
     // the carve kernels are VALU-issue bound, the expansion is memory bound: on its own stream the expansion of this
     // step runs beside the carve of the next one (two steps in flight) instead of after it
-    hipStream_t s2 = (ctx->overlap && !ctx->comm) ? ctx->stream2 : ctx->stream;
-    if (s2 != ctx->stream) VC_HIP(ctx, hipStreamWaitEvent(s2, sb.e1, 0));
+    // (the small scan kernels stay on the first stream, right behind the carve: on the second they would queue for
+    // compute units against the next carve's thousands of workgroups and delay the expansion they feed)
+    hipStream_t s3 = (ctx->overlap && !ctx->comm) ? ctx->stream2 : ctx->stream;
+    hipStream_t s2 = ctx->stream;
     // kernels that do not know their group totals (fused, generic) get them counted
     const bool counted = fast && (mode == VC_MODE_LUT || (ctx->ny % 64 == 0 && ctx->fused_hier));
     if (!counted) {
@@ -1150,13 +1154,17 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     e.records = sb.records.ptr;
     e.capacity = sb.records.cap;
     e.busylist = sb.busylist.ptr; e.busycount = sb.busyblock.ptr;
-    if (!sb.no_records) VC_TRY(launch_emit(ctx, sb, s2));
+    if (s3 != ctx->stream && !sb.no_records) {
+        VC_HIP(ctx, hipEventRecord(sb.e_scan, ctx->stream));
+        VC_HIP(ctx, hipStreamWaitEvent(s3, sb.e_scan, 0));
+    }
+    if (!sb.no_records) VC_TRY(launch_emit(ctx, sb, s3));
     if (auto_exchange) {
         VC_TRY(enqueue_pack(ctx, sb));
         VC_TRY(enqueue_counts_exchange(ctx, sb));
         sb.counts_exchanged = true;
     }
-    VC_HIP(ctx, hipEventRecord(sb.e2, s2));
+    VC_HIP(ctx, hipEventRecord(sb.e2, sb.no_records ? s2 : s3));
     sb.pending = true;
     sb.used = true;
     ctx->head ^= 1;
