@@ -61,3 +61,19 @@ def random_scene(seed, C=3, H=37, W=53, fg=0.4):
     masks = [np.where(rng.random((H, W)) < fg, rng.integers(1, 256, (H, W)), 0).astype(np.uint8) for _ in range(C)]
     frames = [rng.integers(0, 256, (H, W, 3), dtype=np.uint8) for _ in range(C)]
     return cams, masks, frames
+
+
+def arrow_tips():
+    """The reference-held cv2.projectPoints pin (tests/golden/make_arrow_tips.py): world points [3,3] and,
+    per camera, the integer arrow-tip pixels [3,2] measured in the reference's data/cam*/test.jpg."""
+    t = json.load(open(os.path.join(GOLDEN, "arrow_tips.json")))
+    return np.array(t["object_points"], dtype=np.float64), [np.array(c["tips_xy"], dtype=np.float64) for c in t["cameras"]]
+
+
+ARROW_TIP_TOL_PX = 2.0     # 2-px pen, JPEG chroma blur, the reference's int32 truncation
+
+
+def arrow_tip_error(project, cams):
+    """max over cameras / tips of the Chebyshev distance between project(cam_index, cam, points) and the drawn tip."""
+    pts, tips = arrow_tips()
+    return max(float(np.abs(np.asarray(project(c, cam, pts)) - tips[c]).max()) for c, cam in enumerate(cams))

@@ -42,6 +42,16 @@ def test_axes_are_numpy_linspace(eng):
         assert np.array_equal(zs, np.linspace(-2048, 512, num=grid[2]))
 
 
+def test_device_projection_hits_reference_arrow_tips(eng, cams, masks):
+    """The device projection (vc_project) against the only cv2.projectPoints output the reference holds: the arrow
+    tips drawn into data/cam{1..4}/test.jpg (camera_calibration.py:753-789; tests/golden/make_arrow_tips.py).
+    All 12 within 2 px -- a pin that does not descend from the oracle."""
+    eng.set_grid(8, 8, 8)
+    eng.set_cameras(cams, *masks[0].shape)
+    err = fx.arrow_tip_error(lambda c, cam, p: eng.project(c, p), cams)
+    assert err <= fx.ARROW_TIP_TOL_PX, err
+
+
 def test_device_projection_bits_equal_oracle(eng, cams, masks):
     """float64 (u, v) out of the kernel == the numpy restatement, bit for bit."""
     from oracle import carve_np

@@ -63,6 +63,38 @@ def test_projected_samples_golden(built, cams):
         assert np.array_equal(carve_c.project(pts, (cam.K, cam.dist, cam.R, cam.tvec)), want)
 
 
+def test_oracle_pinned_by_reference_arrow_tips(built, cams):
+    """THE reference-produced pin of the oracle: the arrow tips the reference drew into data/cam{1..4}/test.jpg are
+    cv2.projectPoints([[345,0,0],[0,345,0],[0,0,-345]], rvec, tvec, mtx, dist).astype(int32) for exactly the
+    committed cameras (camera_calibration.py:753-789, 847-849, 967-974; fixture: tests/golden/make_arrow_tips.py).
+    Every restatement must land within 2 px on all 12 tips.  Pins the K / distortion / Rodrigues / translation
+    conventions and the axis order at pixel tolerance; cannot pin the last ulp."""
+    from voxcarve.camera import Camera
+    tol = fx.ARROW_TIP_TOL_PX
+    e_np = fx.arrow_tip_error(lambda c, cam, p: carve_np.project_points(p, cam.R, cam.tvec, cam.K, cam.dist), cams)
+    e_c = fx.arrow_tip_error(lambda c, cam, p: carve_c.project(p, (cam.K, cam.dist, cam.R, cam.tvec)), cams)
+    # and with R recomputed from rvec by both Rodrigues restatements (oracle's and the product host's)
+    e_rod = fx.arrow_tip_error(lambda c, cam, p: carve_np.project_points(p, carve_np.rodrigues(cam.rvec), cam.tvec, cam.K, cam.dist), cams)
+    e_host = fx.arrow_tip_error(lambda c, cam, p: carve_np.project_points(p, Camera(cam.K, cam.dist, cam.rvec, cam.tvec).R, cam.tvec, cam.K, cam.dist), cams)
+    assert e_np <= tol and e_c <= tol and e_rod <= tol and e_host <= tol, (e_np, e_c, e_rod, e_host)
+    # the reference truncates (astype(int32) of the float32 result): the truncated pixels agree as well
+    e_tr = fx.arrow_tip_error(lambda c, cam, p: np.trunc(carve_np.project_points(p, cam.R, cam.tvec, cam.K, cam.dist).astype(np.float32)), cams)
+    assert e_tr <= tol, e_tr
+    # the pin discriminates: each of these misreadings of the convention misses a tip by far more than the tolerance
+    wrong = {
+        "R transposed": lambda c, cam, p: carve_np.project_points(p, cam.R.T, cam.tvec, cam.K, cam.dist),
+        "rvec negated": lambda c, cam, p: carve_np.project_points(p, carve_np.rodrigues(-np.asarray(cam.rvec)), cam.tvec, cam.K, cam.dist),
+        "x and y swapped": lambda c, cam, p: carve_np.project_points(p[:, [1, 0, 2]], cam.R, cam.tvec, cam.K, cam.dist),
+        "z sign": lambda c, cam, p: carve_np.project_points(p * [1, 1, -1], cam.R, cam.tvec, cam.K, cam.dist),
+        "t as camera centre": lambda c, cam, p: carve_np.project_points(p - np.asarray(cam.tvec).reshape(1, 3), cam.R, np.zeros(3), cam.K, cam.dist),
+        "no distortion": lambda c, cam, p: carve_np.project_points(p, cam.R, cam.tvec, cam.K, np.zeros(5)),
+        "k1 sign": lambda c, cam, p: carve_np.project_points(p, cam.R, cam.tvec, cam.K, np.asarray(cam.dist).reshape(-1) * [-1, 1, 1, 1, 1]),
+        "fx/fy swapped with cx/cy": lambda c, cam, p: carve_np.project_points(p, cam.R, cam.tvec, np.asarray(cam.K).T[::-1, ::-1].copy(), cam.dist),
+    }
+    for name, f in wrong.items():
+        assert fx.arrow_tip_error(f, cams) > 2 * tol, name
+
+
 @pytest.mark.parametrize("n", [64, 128])
 def test_carve_matches_golden(built, cams, masks, frames, n):
     idx, bgr, summary = fx.expected(n)
