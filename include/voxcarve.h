@@ -69,6 +69,9 @@ typedef struct {
     float exchange_ms;  /* vc_allgather, compact form: pack + RCCL part of gather_ms         */
     float gather_ms_sum; /* summed since vc_timing_reset                                */
     uint32_t gathers;   /* vc_allgather calls since vc_timing_reset                      */
+    float prep_ms;      /* per-frame preparation queued in front of the last carve (bit-pack, boxes, grids, camera order) */
+    float prep_ms_sum;  /* summed since vc_timing_reset                                  */
+    uint32_t preps;     /* carve steps that had to prepare their frame set since vc_timing_reset */
 } vc_timing_t;
 
 /* ---- lifetime ------------------------------------------------------------------ */
@@ -95,16 +98,25 @@ int vc_set_cameras(vc_ctx *ctx, uint32_t n_cameras, const double *K9, const doub
 
 /* ---- per-frame inputs: the fg_masks / images arguments of ------------------------
  *      update_visible_voxels_and_extract_colors, voxel_reconstruction.py:89 --------- */
-/* masks: u8 [C,H,W], foreground where > 0 (line 112).  Bit-packed on the device.
- * slot selects one of the resident frame sets (0..n-1, created on first use). */
+/* masks: u8 [C,H,W], foreground where > 0 (line 112).  slot selects one of the resident frame sets (0..63, created
+ * on first use).  ASYNCHRONOUS: the bytes are copied to a page-locked staging buffer and from there to the device
+ * on an upload stream of their own, so the call returns at once and the copy runs beside the carve in flight; the
+ * caller's buffer is free when the call returns.  Everything derived from the bytes (bit masks, foreground boxes,
+ * cropped block grids, camera visiting order, BGRX images) is made ON THE DEVICE by two kernels queued in front of
+ * the first vc_carve / vc_carve_begin that uses the slot -- no host round trip anywhere. */
 int vc_upload_masks(vc_ctx *ctx, uint32_t slot, const uint8_t *masks);
+/* The byte masks and images resident in `slot` are to be taken as NEW input: the next carve on the slot derives
+ * everything from them again (what a producer that writes the masks on the device, or a benchmark that wants every
+ * step to pay for its own preparation, calls instead of uploading the same bytes again). */
+int vc_touch_masks(vc_ctx *ctx, uint32_t slot);
 /* Tail of extract_foreground_mask on the device (background_subtraction.py:195-206): per camera,
  * optional 2x2 MORPH_OPEN then 2x2 MORPH_CLOSE applied to the byte masks of every following
  * vc_upload_masks, before the final > 0 binarisation.  Arrays of C flags, NULL = none. */
 int vc_set_mask_postfilter(vc_ctx *ctx, const uint8_t *open2x2, const uint8_t *close2x2);
 /* The device's binarised mask of one camera as u8 [H,W] in {0,255} (tests). */
 int vc_fetch_mask(vc_ctx *ctx, uint32_t slot, uint32_t cam, uint8_t *out);
-/* bgr: u8 [H,W,3] image of camera cam (0-based) for colour sampling (lines 119-122). */
+/* bgr: u8 [H,W,3] image of camera cam (0-based) for colour sampling (lines 119-122).  Asynchronous like
+ * vc_upload_masks. */
 int vc_upload_frame(vc_ctx *ctx, uint32_t slot, uint32_t cam, const uint8_t *bgr);
 
 /* ---- lookup table: replaces create_lookup_table, voxel_reconstruction.py:62-86 --- */
@@ -125,7 +137,10 @@ int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int 
 /* The same step split in two so that step i+1 is queued on the device before the host collects
  * step i (no idle gap between steps).  At most two steps may be in flight;
  * vc_carve_end completes the OLDEST one, whose records are then what vc_fetch_* / vc_allgather
- * read until the next vc_carve_end (fetch them before beginning two more steps). */
+ * read.  The two steps alternate between two sets of result buffers: with another step already in flight, the NEXT
+ * vc_carve_begin is queued into the set that holds the collected result, so fetch it before that call -- afterwards
+ * the vc_fetch_* functions fail with VC_ERR_ARG until the next vc_carve_end.
+ * min_views > n_cameras is legal and yields the empty result (as the reference's threshold test would). */
 int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int mode, uint32_t flags);
 int vc_carve_end(vc_ctx *ctx, uint64_t *n_out);
 /* Survivors of the last carve: idx u32 [S] (global linear index, ascending), rgb u8 [S,3]

@@ -380,6 +380,99 @@ def test_simulated_slab_split_equals_full_grid(eng, cams, masks, frames):
     assert eng.carve() == 0
 
 
+def test_stream_of_fresh_mask_sets_through_begin_end(eng, cams, masks, frames):
+    """A stream of 12 DISTINCT mask sets (no two steps see the same input) through vc_carve_begin / vc_carve_end,
+    two steps in flight, uploads racing the carves on the upload stream, only 3 slots recycled: every step's
+    preparation (bit-pack, foreground boxes, cropped block grids, camera order, BGRX image) happens on the device
+    in front of its carve, and every result equals the oracle's for THAT mask set."""
+    from oracle import carve_c
+    grid = (128, 128, 128)
+    H, W = masks[0].shape
+    eng.set_grid(*grid)
+    eng.set_cameras(cams, H, W)
+    eng.build_lut()
+    rng = np.random.default_rng(11)
+    sets = []
+    for k in range(12):
+        ms = [np.roll(np.roll(m, int(rng.integers(-40, 40)), axis=1), int(rng.integers(-25, 25)), axis=0) for m in masks]
+        if k == 5:
+            ms[2] = np.zeros_like(ms[2])                      # a camera without foreground in the middle of the stream
+        if k == 8:
+            ms = [np.where(rng.random((H, W)) < 0.01, 255, m).astype(np.uint8) for m in ms]   # salt noise: nothing to crop
+        fr = np.roll(frames[1], 5 * k, axis=0)
+        sets.append((ms, fr))
+    oc = fx.oracle_cams(cams)
+    for mode in ("lut", "fused"):
+        got = []
+        eng.upload_masks(sets[0][0], slot=0)
+        eng.upload_frame(1, sets[0][1], slot=0)
+        eng.carve_begin(slot=0, mode=mode)
+        for k in range(1, 12):
+            eng.upload_masks(sets[k][0], slot=k % 3)
+            eng.upload_frame(1, sets[k][1], slot=k % 3)
+            eng.carve_begin(slot=k % 3, mode=mode)
+            n = eng.carve_end()
+            rec = eng.fetch_records()
+            assert rec.size == n
+            got.append(rec)
+        eng.carve_end()
+        got.append(eng.fetch_records())
+        assert eng.timing()["preps"] >= 1
+        for k, (ms, fr) in enumerate(sets):
+            fs = list(frames)
+            fs[1] = fr
+            want = carve_c.carve(*grid, oc, ms, fs)
+            idx, rgb, seen = voxcarve_unpack(got[k])
+            assert np.array_equal(idx, want["idx"]), (mode, k)
+            assert np.array_equal(rgb[:, ::-1], want["bgr"]), (mode, k)
+            assert seen.all()
+    # the same bytes taken as new input again (vc_touch_masks) re-derive the same state
+    eng.carve(slot=2, mode="lut")
+    a = eng.fetch_records()
+    eng.touch_masks(slot=2)
+    eng.carve(slot=2, mode="lut")
+    assert eng.timing()["prep_ms"] > 0
+    assert np.array_equal(a, eng.fetch_records())
+
+
+def voxcarve_unpack(rec):
+    from voxcarve.engine import unpack_records
+    return unpack_records(rec)
+
+
+def test_fetch_after_the_result_buffers_were_reissued_fails(eng, cams, masks, frames):
+    """begin A, begin B, end (-> A collected), begin C: C is queued into A's buffers, so A can no longer be
+    fetched -- an error, never a mix of two steps."""
+    from voxcarve._lib import VoxcarveError
+    setup_real(eng, cams, masks, frames, (64, 64, 64))
+    eng.carve_begin()
+    eng.carve_begin()
+    n = eng.carve_end()
+    assert eng.fetch_records().size == n                        # still A's records
+    eng.carve_begin()
+    for f in (eng.fetch_records, eng.fetch, eng.fetch_occupancy, eng.pack_entries):
+        with pytest.raises(VoxcarveError, match="no carve result"):
+            f()
+    assert eng.carve_end() == n and eng.fetch_records().size == n
+    assert eng.carve_end() == n
+
+
+def test_threshold_above_camera_count_is_empty_on_every_path(eng, cams, masks, frames):
+    """min_views > C: the reference's `sum(views.values()) >= views_threshold` (assignment.py:121) is never true."""
+    from oracle import carve_np
+    setup_real(eng, cams, masks, frames, (64, 64, 64))
+    eng.build_lut()
+    want = carve_np.carve(64, 64, 64, fx.oracle_cams(cams), masks, frames, min_views=5)
+    assert want["idx"].size == 0
+    for mode in ("lut", "fused"):
+        for generic in (0, 1):
+            eng.set_option("force_generic", generic)
+            for vm in (False, True):
+                assert eng.carve(mode=mode, min_views=5, viewmask=vm) == 0
+                assert eng.fetch()[0].size == 0 and not eng.fetch_occupancy().any()
+    eng.set_option("force_generic", 0)
+
+
 def test_overlapped_steps_begin_end(eng, cams, masks, frames):
     """Two steps in flight (step i+1 queued before step i is collected) give the records of the
     one-at-a-time calls, in order, for both modes."""
@@ -730,17 +823,21 @@ def test_bench_contract_single_gpu(built):
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert d["config"]["survivors"] == 461113                      # the 256^3 golden count: the bench ran the real path
+    # every timed step prepared its frame set on the device, inside the timed region; the PCIe-inclusive figure is there
+    ph = d["phases_ms"]
+    assert ph["steps_that_prepared"] == 7 and 0 < ph["frame_set_prep_on_device"] < d["ms_per_step"]
+    assert d["pcie_inclusive"]["value"] > 0 and d["pcie_inclusive"]["value"] < d["value"]
 
 
 def test_bench_two_ranks_host_transport(built):
     """The N > 1 flow of bench.py (work-balanced slab bounds, records-free steps, compact word exchange, expansion of
     all ranks' words on the device) with two processes sharing this GPU; the exchange itself goes through gloo
     because RCCL refuses two ranks on one device.  The gathered list must be the single-rank one."""
-    d = _run_bench(["--grid", "256", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--single-device",
+    d = _run_bench(["--grid", "256", "--steps", "8", "--warmup", "1", "--no-cpu-baseline", "--single-device",
                     "--transport", "host"], nproc=2, timeout=600)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["cpu_baseline"] is None
     assert "balanced" in d["config"]["split"] and "host" in d["config"]["exchange"]
-    # frame sets are rolled per step: the last timed step (index warmup + steps - 1 = 4 -> slot 0) is the unrolled set
+    # frame sets are rolled per step: the last timed step (index warmup + steps - 1 = 8 -> slot 0) is the unrolled set
     assert d["config"]["survivors"] == 461113
     for m in d["other_modes"].values():
         assert m["survivors"] == 461113

@@ -36,7 +36,8 @@ class VcTiming(ctypes.Structure):
                 ("survivors", ctypes.c_uint64), ("carve_launches", ctypes.c_uint32),
                 ("carve_ms_sum", ctypes.c_float), ("first_ms", ctypes.c_float),
                 ("first_ms_sum", ctypes.c_float), ("exchange_ms", ctypes.c_float),
-                ("gather_ms_sum", ctypes.c_float), ("gathers", ctypes.c_uint32)]
+                ("gather_ms_sum", ctypes.c_float), ("gathers", ctypes.c_uint32),
+                ("prep_ms", ctypes.c_float), ("prep_ms_sum", ctypes.c_float), ("preps", ctypes.c_uint32)]
 
 
 # name -> (restype, argtypes); every symbol include/voxcarve.h declares.
@@ -52,6 +53,7 @@ SIGNATURES = {
     "vc_set_cameras": (ctypes.c_int, [c_ctx, ctypes.c_uint32, c_f64p, c_f64p, c_f64p, c_f64p,
                                       ctypes.c_uint32, ctypes.c_uint32]),
     "vc_upload_masks": (ctypes.c_int, [c_ctx, ctypes.c_uint32, c_u8p]),
+    "vc_touch_masks": (ctypes.c_int, [c_ctx, ctypes.c_uint32]),
     "vc_set_mask_postfilter": (ctypes.c_int, [c_ctx, c_u8p, c_u8p]),
     "vc_fetch_mask": (ctypes.c_int, [c_ctx, ctypes.c_uint32, ctypes.c_uint32, c_u8p]),
     "vc_upload_frame": (ctypes.c_int, [c_ctx, ctypes.c_uint32, ctypes.c_uint32, c_u8p]),

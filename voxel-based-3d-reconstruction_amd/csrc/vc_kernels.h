@@ -7,7 +7,7 @@
 // grid shape allows, a tile of 4 x-rows x 16 y (compact footprint, tighter pixel box); results always
 // leave the kernels as y-major words.
 //
-//   per frame set   k_pack_masks, k_morph2x2, k_mask_bbox, k_blockgrid, k_expand_frame, k_estimate
+//   per frame set   k_morph2x2 (optional), k_prep_pack, k_prep_grid: two launches, nothing returns to the host
 //   per geometry    k_build_lut<TILE> (table and/or word boxes), k_tile_lut
 //   carve           k_lut_refine<B,HIER,PAIR,TILE>   hierarchical lookup-table kernel (default VC_MODE_LUT)
 //                   k_carve_fused_hier<TILE,BOX>     the same with the projection in-kernel (default VC_MODE_FUSED)
@@ -41,9 +41,19 @@ struct GridCam {
     uint16_t w_lo, v_lo, cws, ch;
 };
 
-// The grid buffer starts with the cameras' descriptors (3 words each) so that kernels index them in LDS --
-// indexing the kernel-argument copy with a run-time camera number costs the compiler 48 VGPRs.
-constexpr uint32_t kGridHeader = 3 * kMaxCameras;
+// A frame set's grid buffer starts with a HEADER the per-frame preparation kernels write on the device (nothing
+// of a frame set's derived state ever visits the host): the cameras' grid descriptors (3 words each; kernels
+// index them in LDS -- indexing a kernel-argument copy with a run-time camera number costs the compiler 48
+// VGPRs), the block size and buffer length the preparation chose, and the camera visiting order.
+constexpr uint32_t kHdrShift = 3 * kMaxCameras;        // log2 of the block edge in pixels
+constexpr uint32_t kHdrWords = kHdrShift + 1;          // u32 words of header + grids (what the hierarchical kernels stage in LDS)
+constexpr uint32_t kHdrGridWgs = kHdrShift + 2;        // workgroups of k_prep_grid with blocks to classify (its ticket total)
+constexpr uint32_t kHdrOrder = kHdrShift + 4;          // kMaxCameras camera numbers, most selective first
+constexpr uint32_t kGridHeader = kHdrOrder + kMaxCameras;   // 68 words = 17 x 16 bytes
+__device__ __forceinline__ uint32_t hdr_u32(const uint32_t *hdr, uint32_t i)          // wave-uniform i
+{
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr[i]);
+}
 __device__ __forceinline__ GridCam load_gridcam(const uint32_t *grids, uint32_t c)
 {
     const uint32_t a = (uint32_t)__builtin_amdgcn_readfirstlane((int)grids[3 * c]);          // c is wave-uniform
@@ -61,9 +71,8 @@ struct CarveParams {
     const uint64_t *tbox;       // [C][n_pad/64] pixel boxes of the tile words
     uint32_t tq;                // tile words per row quad = ny / 16
     uint32_t tile_whole;        // 64 % tq == 0: the 64 tile words of a wave are exactly one y-major group
-    const uint32_t *blockgrid;  // per camera (crop[c].off): any[ch][cws] then all[ch][cws], one bit per 2^gshift-pixel block
-    uint32_t gshift;            // block size of this frame set's grids
-    uint32_t grid_words;        // u32 words of descriptors + grids (what the hierarchical kernels stage in LDS)
+    const uint32_t *blockgrid;  // the frame set's header (block size, length, camera order) + per camera (crop[c].off):
+                                // any[ch][cws] then all[ch][cws], one bit per block of 2^shift x 2^shift pixels
     uint64_t *words;
     uint32_t *groupcnt;         // survivors per group of 64 words (kernels that know it write it)
     uint16_t *viewmask;
@@ -72,7 +81,6 @@ struct CarveParams {
     uint32_t nx, ny, nz, z0;
     uint32_t C, H, W, mwords;
     uint32_t min_views;
-    uint32_t order[kMaxCameras];   // camera visiting order (most selective first)
     CamDev cam[kMaxCameras];
 };
 
@@ -108,35 +116,6 @@ __device__ __forceinline__ void decompose(uint32_t j, uint32_t nx, uint32_t ny,
     ix = t - izl * nx;
 }
 
-// ---------------------------------------------------------------- mask bit-packing
-// One thread per output word: 32 mask bytes -> 32 bits (foreground where byte > 0,
-// voxel_reconstruction.py:112).
-__global__ __launch_bounds__(kBlock) void k_pack_masks(const uint8_t *__restrict__ bytes,
-                                                       uint32_t *__restrict__ bits,
-                                                       uint32_t C, uint32_t HW, uint32_t mwords)
-{
-    const uint32_t w = blockIdx.x * kBlock + threadIdx.x;
-    const uint32_t c = blockIdx.y;
-    if (w >= mwords || c >= C) return;
-    const uint8_t *src = bytes + (size_t)c * HW;
-    const uint32_t p0 = w * 32u;
-    uint32_t out = 0;
-    if (p0 + 32u <= HW && ((reinterpret_cast<uintptr_t>(src + p0) & 3u) == 0)) {
-        const uint32_t *s4 = reinterpret_cast<const uint32_t *>(src + p0);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const uint32_t v = s4[q];
-            out |= ((v & 0x000000ffu) ? 1u : 0u) << (4 * q + 0);
-            out |= ((v & 0x0000ff00u) ? 1u : 0u) << (4 * q + 1);
-            out |= ((v & 0x00ff0000u) ? 1u : 0u) << (4 * q + 2);
-            out |= ((v & 0xff000000u) ? 1u : 0u) << (4 * q + 3);
-        }
-    } else {
-        for (uint32_t b = 0; b < 32u && p0 + b < HW; ++b) out |= (src[p0 + b] ? 1u : 0u) << b;
-    }
-    bits[(size_t)c * mwords + w] = out;
-}
-
 // ---------------------------------------------------------------- mask post-filter
 // One pass of cv2.erode / cv2.dilate with the 2x2 MORPH_RECT element the reference applies after
 // contour filling (background_subtraction.py:195-203): OpenCV anchors an even element at ksize/2,
@@ -154,28 +133,6 @@ __global__ __launch_bounds__(kBlock) void k_morph2x2(const uint8_t *__restrict__
     if (y > 0) { const uint32_t o = in[i - W]; v = DILATE ? (o > v ? o : v) : (o < v ? o : v); }
     if (x > 0 && y > 0) { const uint32_t o = in[i - W - 1]; v = DILATE ? (o > v ? o : v) : (o < v ? o : v); }
     out[i] = (uint8_t)v;
-}
-
-// ---------------------------------------------------------------- camera selectivity
-// Pass count of each camera on `nsamples` evenly spaced voxels of the slab: the host
-// sorts cameras by it so the carve visits the most selective camera first.  Changes
-// the work done, never the result (the all-views test is a conjunction).
-__global__ __launch_bounds__(kBlock) void k_estimate(const CarveParams p, uint32_t *__restrict__ counts,
-                                                     uint32_t nsamples)
-{
-    const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
-    const bool valid = s < nsamples;
-    uint32_t ix = 0, iy = 0, izl = 0;
-    if (valid) decompose((uint32_t)(((uint64_t)s * p.n) / nsamples), p.nx, p.ny, ix, iy, izl);
-    const double X = p.xs[ix], Y = p.ys[iy], Z = p.zs[p.z0 + izl];
-    for (uint32_t c = 0; c < p.C; ++c) {
-        double u, v;
-        project_point(p.cam[c], X, Y, Z, u, v);
-        const int32_t off = pixel_offset(u, v, p.H, p.W);
-        const bool hit = valid && off >= 0 && mask_bit(p.maskbits + (size_t)c * p.mwords, off);
-        const uint64_t b = __ballot(hit);
-        if ((threadIdx.x & 63u) == 0 && b) atomicAdd(&counts[c], (uint32_t)__popcll(b));
-    }
 }
 
 // ---------------------------------------------------------------- generic carve
@@ -262,7 +219,7 @@ template <int KV>
 __global__ __launch_bounds__(kFirstBlock) void k_lut_first(const CarveParams p)
 {
     extern __shared__ uint32_t s_mask[];                         // first camera's mask bits
-    const uint32_t c0 = p.order[0];
+    const uint32_t c0 = hdr_u32(p.blockgrid, kHdrOrder);
     {
         const uint32_t *__restrict__ mb = p.maskbits + (size_t)c0 * p.mwords;
         for (uint32_t i = threadIdx.x; i < p.mwords; i += kFirstBlock) s_mask[i] = mb[i];
@@ -408,12 +365,15 @@ __device__ __forceinline__ void tile_store(const CarveParams &p, uint32_t g, uin
 template <int B, bool HIER, bool PAIR, bool TILE = false>
 __device__ __forceinline__ void lut_refine_body(const CarveParams &p, uint32_t vblock, uint32_t nblocks, uint32_t *s_grid)
 {
-    if (HIER) {                                                   // the grids into LDS, 16 bytes per lane (buffer padded to 16 B)
+    if (HIER) {                                                   // header + grids into LDS, 16 bytes per lane (buffer padded to 16 B)
         const uint4 *src = reinterpret_cast<const uint4 *>(p.blockgrid);
         uint4 *dst = reinterpret_cast<uint4 *>(s_grid);
-        for (uint32_t i = threadIdx.x; i < (p.grid_words + 3) / 4; i += kBlock) dst[i] = src[i];
+        const uint32_t gwords = hdr_u32(p.blockgrid, kHdrWords);
+        for (uint32_t i = threadIdx.x; i < (gwords + 3) / 4; i += kBlock) dst[i] = src[i];
         __syncthreads();
     }
+    const uint32_t *hdr = HIER ? s_grid : p.blockgrid;            // camera order (and block size) of this frame set
+    const uint32_t gshift = HIER ? hdr_u32(s_grid, kHdrShift) : 0u;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane((vblock * kBlock + threadIdx.x) >> 6);
     const uint32_t nwaves = nblocks * (kBlock / 64);
@@ -434,11 +394,11 @@ __device__ __forceinline__ void lut_refine_body(const CarveParams &p, uint32_t v
                 uint64_t bb[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    bb[k] = (q0 + k < p.C) ? (TILE ? p.tbox : p.bbox)[(size_t)p.order[q0 + k] * nwords + gw + lane] : 0ull;
+                    bb[k] = (q0 + k < p.C) ? (TILE ? p.tbox : p.bbox)[(size_t)hdr_u32(hdr, kHdrOrder + q0 + k) * nwords + gw + lane] : 0ull;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (q0 + k < p.C && cand) {
-                        const uint32_t r = box_test(s_grid, load_gridcam(s_grid, p.order[q0 + k]), bb[k], p.gshift);
+                        const uint32_t r = box_test(s_grid, load_gridcam(s_grid, hdr_u32(hdr, kHdrOrder + q0 + k)), bb[k], gshift);
                         cand = r != 0;
                         if (r == 1) need |= 1u << (q0 + k);
                     }
@@ -478,7 +438,7 @@ __device__ __forceinline__ void lut_refine_body(const CarveParams &p, uint32_t v
                 // PAIR: two cameras' entries per dependent round trip (their loads and gathers overlap)
                 if (((ndany >> q) & (PAIR ? 3u : 1u)) == 0) continue;   // decided by the boxes for the whole batch
                 const bool two = PAIR && q + 1 < p.C;
-                const uint32_t c = p.order[q], c2 = p.order[two ? q + 1 : q];
+                const uint32_t c = hdr_u32(hdr, kHdrOrder + q), c2 = hdr_u32(hdr, kHdrOrder + (two ? q + 1 : q));
                 const int32_t *__restrict__ L = (TILE ? p.lut_tile : p.lut) + (size_t)c * p.n_pad + gw * 64 + lane;
                 const int32_t *__restrict__ L2 = (TILE ? p.lut_tile : p.lut) + (size_t)c2 * p.n_pad + gw * 64 + lane;
                 const uint32_t *__restrict__ mb = p.maskbits + (size_t)c * p.mwords;
@@ -587,7 +547,7 @@ __global__ __launch_bounds__(kBlock) void k_carve_fused(const CarveParams p)
             }
         }
         for (uint32_t q = 0; q < p.C; ++q) {
-            const uint32_t c = p.order[q];
+            const uint32_t c = hdr_u32(p.blockgrid, kHdrOrder + q);
             const uint32_t *__restrict__ mb = p.maskbits + (size_t)c * p.mwords;
 #pragma unroll
             for (int k = 0; k < KSUB; ++k) {
@@ -754,9 +714,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(p.blockgrid);
         uint4 *dst = reinterpret_cast<uint4 *>(s_grid);
-        for (uint32_t i = threadIdx.x; i < (p.grid_words + 3) / 4; i += kBlock) dst[i] = src[i];
+        const uint32_t gwords = hdr_u32(p.blockgrid, kHdrWords);
+        for (uint32_t i = threadIdx.x; i < (gwords + 3) / 4; i += kBlock) dst[i] = src[i];
         __syncthreads();
     }
+    const uint32_t gshift = hdr_u32(s_grid, kHdrShift);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
     const uint32_t nwaves = gridDim.x * (kBlock / 64);
@@ -784,11 +746,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                 uint64_t bb[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    bb[k] = (q0 + k < p.C) ? (TILE ? p.tbox : p.bbox)[(size_t)p.order[q0 + k] * nwords + gw + lane] : 0ull;
+                    bb[k] = (q0 + k < p.C) ? (TILE ? p.tbox : p.bbox)[(size_t)hdr_u32(s_grid, kHdrOrder + q0 + k) * nwords + gw + lane] : 0ull;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (q0 + k < p.C && cand) {
-                        const uint32_t r = box_test(s_grid, load_gridcam(s_grid, p.order[q0 + k]), bb[k], p.gshift);
+                        const uint32_t r = box_test(s_grid, load_gridcam(s_grid, hdr_u32(s_grid, kHdrOrder + q0 + k)), bb[k], gshift);
                         cand = r != 0;
                         if (r == 1) need |= 1u << (q0 + k);
                     }
@@ -796,13 +758,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             }
         }
         for (uint32_t q = 0; BOX != 2 && q < p.C && __ballot(cand) != 0; ++q) {
-            const uint32_t c = p.order[q];
+            const uint32_t c = hdr_u32(s_grid, kHdrOrder + q);
             if (cand) {
                 const uint64_t bb = BOX == 1 ? segment_box_f32(p.cam[c], xa, xb, ya, yb, Z, p.H, p.W)
                                              : segment_box(p.cam[c], xa, xb, ya, yb, Z, p.H, p.W);
                 uint32_t r = 1;
                 if (bb != kMaybeBox) {
-                    r = box_test(s_grid, load_gridcam(s_grid, c), bb, p.gshift);
+                    r = box_test(s_grid, load_gridcam(s_grid, c), bb, gshift);
                 }
                 cand = r != 0;
                 if (r == 1) need |= 1u << q;
@@ -824,7 +786,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             bool alive = true;
             for (uint32_t q = 0; q < p.C; ++q) {
                 if (!((nd >> q) & 1u)) continue;                  // decided for the whole word by its box
-                const uint32_t c = p.order[q];
+                const uint32_t c = hdr_u32(s_grid, kHdrOrder + q);
                 if (alive) {
                     double u, v;
                     project_point(p.cam[c], VX, VY, VZ, u, v);
@@ -866,6 +828,16 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(v, d); v = o > v ? o : v; }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(v, d);
+        if (lane >= (uint32_t)d) v += o;
+    }
     return v;
 }
 
@@ -946,70 +918,6 @@ __global__ __launch_bounds__(kBlock) void k_tile_lut(const CarveParams p, const 
     }
 }
 
-// Pixel bounding box of each camera's foreground: out[4c..] = u_min, u_max, v_min, v_max (u_min > u_max: none).
-// One workgroup per camera.
-__global__ __launch_bounds__(kBlock) void k_mask_bbox(const uint32_t *__restrict__ maskbits, uint32_t mwords, uint32_t H,
-                                                      uint32_t W, uint32_t *__restrict__ out)
-{
-    __shared__ uint32_t s[4];
-    const uint32_t c = blockIdx.x;
-    if (threadIdx.x == 0) { s[0] = 0xffffffffu; s[1] = 0; s[2] = 0xffffffffu; s[3] = 0; }
-    __syncthreads();
-    const uint32_t *mb = maskbits + (size_t)c * mwords;
-    uint32_t u0 = 0xffffffffu, u1 = 0, v0 = 0xffffffffu, v1 = 0;
-    for (uint32_t w = threadIdx.x; w < mwords; w += kBlock) {
-        uint32_t bits = mb[w];
-        while (bits) {
-            const uint32_t o = w * 32 + (uint32_t)__builtin_ctz(bits);
-            bits &= bits - 1;
-            if (o >= H * W) break;
-            const uint32_t v = o / W, u = o - v * W;
-            u0 = u < u0 ? u : u0; u1 = u > u1 ? u : u1;
-            v0 = v < v0 ? v : v0; v1 = v > v1 ? v : v1;
-        }
-    }
-    if (u0 != 0xffffffffu) { atomicMin(&s[0], u0); atomicMax(&s[1], u1); atomicMin(&s[2], v0); atomicMax(&s[3], v1); }
-    __syncthreads();
-    if (threadIdx.x < 4) out[4 * c + threadIdx.x] = s[threadIdx.x];
-}
-
-// Two bits per block of 2^gshift x 2^gshift pixels, only for the blocks of crop[c] (see GridCam): "some pixel
-// is foreground" and "every pixel (inside the image) is foreground".  The buffer is zeroed before.
-struct GridBuild {
-    uint32_t H, W, mwords, gshift;
-    GridCam crop[kMaxCameras];
-};
-
-__global__ __launch_bounds__(kBlock) void k_blockgrid(const uint32_t *__restrict__ maskbits, uint32_t *__restrict__ grid,
-                                                      const GridBuild p)
-{
-    const uint32_t c = blockIdx.y;
-    const GridCam gc = p.crop[c];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {                   // the camera's descriptor, as load_gridcam reads it
-        grid[3 * c] = gc.off;
-        grid[3 * c + 1] = (uint32_t)gc.w_lo | ((uint32_t)gc.v_lo << 16);
-        grid[3 * c + 2] = (uint32_t)gc.cws | ((uint32_t)gc.ch << 16);
-    }
-    const uint32_t bw = (uint32_t)gc.cws * 32u;                  // block columns kept
-    const uint32_t b = blockIdx.x * kBlock + threadIdx.x;
-    if (b >= bw * gc.ch) return;
-    const uint32_t rv = b / bw, ru = b - rv * bw;
-    const uint32_t bv = gc.v_lo + rv, bu = (uint32_t)gc.w_lo * 32u + ru;
-    if ((bu << p.gshift) >= p.W || (bv << p.gshift) >= p.H) return;
-    const uint32_t *mb = maskbits + (size_t)c * p.mwords;
-    bool any = false, all = true;
-    for (uint32_t y = bv << p.gshift; y < ((bv + 1) << p.gshift) && y < p.H; ++y)
-        for (uint32_t x = bu << p.gshift; x < ((bu + 1) << p.gshift) && x < p.W; ++x) {
-            const uint32_t o = y * p.W + x;
-            const bool fg = (mb[o >> 5] >> (o & 31u)) & 1u;
-            any = any || fg;
-            all = all && fg;
-        }
-    const uint32_t w = gc.off + rv * gc.cws + (ru >> 5);
-    if (any) atomicOr(&grid[w], 1u << (ru & 31u));
-    if (all) atomicOr(&grid[w + (uint32_t)gc.ch * gc.cws], 1u << (ru & 31u));
-}
-
 __global__ __launch_bounds__(kBlock) void k_project(const CamDev cam, const double *__restrict__ xyz,
                                                     uint64_t n, double *__restrict__ uv)
 {
@@ -1021,18 +929,286 @@ __global__ __launch_bounds__(kBlock) void k_project(const CamDev cam, const doub
     uv[2 * i + 1] = v;
 }
 
+// ---------------------------------------------------------------- per-frame preparation
+// What a new frame set needs before the carve kernels can run on it, in two launches and without a
+// host round trip (the byte masks of update_visible_voxels_and_extract_colors' fg_masks argument,
+// voxel_reconstruction.py:89, are already on the device):
+//
+//  k_prep_pack  byte masks -> bit masks (foreground where byte > 0, voxel_reconstruction.py:112) for all cameras,
+//               BGR images -> one BGRX dword per pixel (a colour sample is then a single aligned load), and each
+//               camera's foreground pixel bounding box (workgroup reduction, then atomics only where they still
+//               move the box).  The LAST workgroup to finish (ticket counter) turns the boxes into the plan of
+//               the cropped block grids -- finest power-of-two block whose grids of all cameras fit the LDS
+//               budget -- and writes it into the frame set's header.
+//  k_prep_grid  the two bits per block ("some pixel is foreground", "every pixel is foreground") of every camera's
+//               cropped grid, written as whole words from ballots (no zero-fill, no atomics), and beside them the
+//               pass counts of each camera on a sample of the slab's voxels; the last workgroup sorts the cameras
+//               by them (most selective first) into the header.  Changes the work done, never the result (the
+//               all-views test is a conjunction).
+//
+// The scratch is self-cleaning: whoever consumes it leaves it as the next launch expects it (boxes empty, counts and
+// tickets zero -- atomicInc wraps the ticket), so no memset sits between the launches.
+constexpr uint32_t kEstPerThread = 4;
+struct PrepScratch {
+    uint32_t bbox[kMaxCameras][4];     // u_min, u_max, v_min, v_max (u_min > u_max: no foreground)
+    uint32_t est[kMaxCameras];
+    uint32_t ticket[2];
+};
+
+struct PrepParams {
+    const uint8_t *src[kMaxCameras];   // byte mask of each camera (as uploaded, or post-filtered)
+    const uint8_t *fsrc[kMaxCameras];  // BGR images to expand (nframes of them) ...
+    uint32_t *fdst[kMaxCameras];       // ... into BGRX
+    uint32_t *bits;                    // [C][mwords]
+    uint32_t *grid;                    // the frame set's header + grids
+    PrepScratch *scratch;
+    uint32_t C, H, W, HW, mwords, nframes;
+    uint32_t min_shift, budget_words;  // finest block, LDS budget of header + grids in u32 words
+};
+
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// true in exactly one workgroup of the launch: the one that finishes last (all others' global writes are visible to it)
+__device__ __forceinline__ bool last_workgroup(uint32_t *ticket, uint32_t total, uint32_t *s_flag)
+{
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *s_flag = (atomicInc(ticket, total - 1u) == total - 1u) ? 1u : 0u;
+    }
+    __syncthreads();
+    const bool last = *s_flag != 0;
+    if (last) __threadfence();
+    return last;
+}
+
+__global__ __launch_bounds__(kBlock) void k_prep_pack(const PrepParams p)
+{
+    __shared__ uint32_t s_red[kBlock / 64][4];
+    __shared__ uint32_t s_flag;
+    // workgroups [0, C * pw): camera y packs 256 mask words each; then fw per image: 1024 pixels each
+    const uint32_t pw = (p.mwords + kBlock - 1) / kBlock, fw = (p.HW + 4 * kBlock - 1) / (4 * kBlock);
+    const bool packing = blockIdx.x < p.C * pw;
+    const uint32_t y = packing ? blockIdx.x / pw : p.C + (blockIdx.x - p.C * pw) / fw;
+    const uint32_t t = (packing ? blockIdx.x - y * pw : (blockIdx.x - p.C * pw) - (y - p.C) * fw) * kBlock + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (packing) {
+        uint32_t u0 = 0xffffffffu, u1 = 0, v0 = 0xffffffffu, v1 = 0;
+        if (t < p.mwords) {
+            const uint8_t *src = p.src[y];
+            const uint32_t p0 = t * 32u;
+            uint32_t out = 0;
+            if (p0 + 32u <= p.HW && ((reinterpret_cast<uintptr_t>(src + p0) & 15u) == 0)) {
+                const uint4 *s16 = reinterpret_cast<const uint4 *>(src + p0);
+                const uint4 a = s16[0], b = s16[1];
+                const uint32_t v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    out |= ((v[q] & 0x000000ffu) ? 1u : 0u) << (4 * q + 0);
+                    out |= ((v[q] & 0x0000ff00u) ? 1u : 0u) << (4 * q + 1);
+                    out |= ((v[q] & 0x00ff0000u) ? 1u : 0u) << (4 * q + 2);
+                    out |= ((v[q] & 0xff000000u) ? 1u : 0u) << (4 * q + 3);
+                }
+            } else {
+                for (uint32_t b = 0; b < 32u && p0 + b < p.HW; ++b) out |= (src[p0 + b] ? 1u : 0u) << b;
+            }
+            p.bits[(size_t)y * p.mwords + t] = out;
+            if (out) {
+                const uint32_t lo = p0 + (uint32_t)__builtin_ctz(out), hi = p0 + 31u - (uint32_t)__builtin_clz(out);
+                v0 = lo / p.W; v1 = hi / p.W;
+                if (v0 == v1) { u0 = lo - v0 * p.W; u1 = hi - v1 * p.W; }
+                else {                                            // the word spans image rows: pixel by pixel
+                    u0 = 0xffffffffu; u1 = 0;
+                    for (uint32_t bits = out; bits; bits &= bits - 1) {
+                        const uint32_t o = p0 + (uint32_t)__builtin_ctz(bits);
+                        const uint32_t u = o - (o / p.W) * p.W;
+                        u0 = u < u0 ? u : u0; u1 = u > u1 ? u : u1;
+                    }
+                }
+            }
+        }
+        u0 = wave_min_u32(u0); u1 = wave_max_u32(u1); v0 = wave_min_u32(v0); v1 = wave_max_u32(v1);
+        if (lane == 0) { s_red[wave][0] = u0; s_red[wave][1] = u1; s_red[wave][2] = v0; s_red[wave][3] = v1; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (uint32_t k = 1; k < kBlock / 64; ++k) {
+                u0 = s_red[k][0] < u0 ? s_red[k][0] : u0; u1 = s_red[k][1] > u1 ? s_red[k][1] : u1;
+                v0 = s_red[k][2] < v0 ? s_red[k][2] : v0; v1 = s_red[k][3] > v1 ? s_red[k][3] : v1;
+            }
+            if (u0 != 0xffffffffu) {                              // boxes only ever grow: skip what would not move them
+                uint32_t *bb = p.scratch->bbox[y];
+                if (u0 < ld_agent(bb + 0)) atomicMin(bb + 0, u0);
+                if (u1 > ld_agent(bb + 1)) atomicMax(bb + 1, u1);
+                if (v0 < ld_agent(bb + 2)) atomicMin(bb + 2, v0);
+                if (v1 > ld_agent(bb + 3)) atomicMax(bb + 3, v1);
+            }
+        }
+    } else {
+        // four pixels per thread: 12 bytes in as three dwords, 16 bytes out
+        const uint8_t *src = p.fsrc[y - p.C];
+        uint32_t *dst = p.fdst[y - p.C];
+        const uint32_t i4 = t * 4u;
+        if (i4 + 4u <= p.HW) {
+            const uint32_t *s4 = reinterpret_cast<const uint32_t *>(src) + 3u * t;
+            const uint32_t w0 = s4[0], w1 = s4[1], w2 = s4[2];
+            uint4 o;
+            o.x = w0 & 0xffffffu;
+            o.y = (w0 >> 24) | ((w1 & 0xffffu) << 8);
+            o.z = (w1 >> 16) | ((w2 & 0xffu) << 16);
+            o.w = w2 >> 8;
+            reinterpret_cast<uint4 *>(dst)[t] = o;
+        } else {
+            for (uint32_t i = i4; i < p.HW; ++i)
+                dst[i] = (uint32_t)src[3 * i] | ((uint32_t)src[3 * i + 1] << 8) | ((uint32_t)src[3 * i + 2] << 16);
+        }
+    }
+    if (!last_workgroup(&p.scratch->ticket[0], gridDim.x, &s_flag)) return;
+    if (wave != 0) return;
+    // ---- plan of the cropped block grids (wave 0 of the last workgroup).  lane = candidate shift: words needed
+    const uint32_t shift_c = lane < 15u ? lane : 14u;
+    uint32_t total = kGridHeader;
+    for (uint32_t c = 0; c < p.C; ++c) {
+        const uint32_t b0 = ld_agent(&p.scratch->bbox[c][0]), b1 = ld_agent(&p.scratch->bbox[c][1]);
+        const uint32_t b2 = ld_agent(&p.scratch->bbox[c][2]), b3 = ld_agent(&p.scratch->bbox[c][3]);
+        if (b0 > b1) continue;
+        const uint32_t cws = ((b1 >> shift_c) >> 5) - ((b0 >> shift_c) >> 5) + 1u;
+        const uint32_t ch = (b3 >> shift_c) - (b2 >> shift_c) + 1u;
+        total += 2u * cws * ch;
+    }
+    // W <= 65535, H <= 32767: at 2^14-pixel blocks every grid is a few words, so a shift is always found
+    const uint64_t fits = __ballot(lane >= p.min_shift && lane < 15u && (total <= p.budget_words || lane == 14u));
+    const uint32_t shift = (uint32_t)__builtin_ctzll(fits);
+    // lane = camera: its descriptor at the chosen shift
+    uint32_t w_lo = 0, v_lo = 0, cws = 0, ch = 0;
+    if (lane < p.C) {
+        const uint32_t b0 = ld_agent(&p.scratch->bbox[lane][0]), b1 = ld_agent(&p.scratch->bbox[lane][1]);
+        const uint32_t b2 = ld_agent(&p.scratch->bbox[lane][2]), b3 = ld_agent(&p.scratch->bbox[lane][3]);
+        if (b0 <= b1) {
+            w_lo = (b0 >> shift) >> 5; cws = ((b1 >> shift) >> 5) - w_lo + 1u;
+            v_lo = b2 >> shift; ch = (b3 >> shift) - v_lo + 1u;
+        }
+    }
+    const uint32_t size = 2u * cws * ch;
+    const uint32_t incl = wave_inclusive_scan(size, lane);
+    if (lane < kMaxCameras) {
+        p.grid[3 * lane] = kGridHeader + incl - size;
+        p.grid[3 * lane + 1] = w_lo | (v_lo << 16);
+        p.grid[3 * lane + 2] = cws | (ch << 16);
+        uint32_t *bb = p.scratch->bbox[lane];                     // leave the scratch empty for the next frame set
+        bb[0] = 0xffffffffu; bb[1] = 0; bb[2] = 0xffffffffu; bb[3] = 0;
+    }
+    // workgroups of k_prep_grid that will have blocks to look at (the others leave without drawing a ticket)
+    uint32_t wgs = (32u * cws * ch + kBlock - 1) / kBlock;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) wgs += __shfl_xor(wgs, d);
+    if (lane == 63) {
+        p.grid[kHdrShift] = shift;
+        p.grid[kHdrWords] = kGridHeader + incl;
+        p.grid[kHdrGridWgs] = wgs;
+    }
+}
+
+// "any" and "all" of the pixels [o, o + len) of a bit mask, len >= 1
+__device__ __forceinline__ void span_any_all(const uint32_t *__restrict__ mb, uint32_t o, uint32_t len, bool &any, bool &all)
+{
+    uint32_t w = o >> 5;
+    const uint32_t wl = (o + len - 1u) >> 5;
+    for (; w <= wl; ++w) {
+        uint32_t m = 0xffffffffu;
+        if (w == (o >> 5)) m &= 0xffffffffu << (o & 31u);
+        if (w == wl) m &= 0xffffffffu >> (31u - ((o + len - 1u) & 31u));
+        const uint32_t v = mb[w];
+        any = any || (v & m) != 0;
+        all = all && (v & m) == m;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_prep_grid(const CarveParams p, uint32_t *__restrict__ grid, PrepScratch *scratch,
+                                                      uint32_t nsamples, uint32_t reorder)
+{
+    __shared__ uint32_t s_flag;
+    const uint32_t y = blockIdx.y;
+    const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (y < p.C) {
+        const GridCam gc = load_gridcam(grid, y);
+        const uint32_t shift = hdr_u32(grid, kHdrShift);
+        const uint32_t bw = (uint32_t)gc.cws * 32u, nb = bw * gc.ch;     // block columns kept, blocks kept
+        if (blockIdx.x * kBlock >= nb) return;                           // (workgroup-uniform; not counted in the ticket)
+        {
+            bool any = false, all = false;
+            if (t < nb) {
+                const uint32_t rv = t / bw, ru = t - rv * bw;
+                const uint32_t bv = gc.v_lo + rv, bu = (uint32_t)gc.w_lo * 32u + ru;
+                const uint32_t x0 = bu << shift, y0 = bv << shift;
+                if (x0 < p.W && y0 < p.H) {
+                    const uint32_t x1 = ((bu + 1u) << shift) < p.W ? ((bu + 1u) << shift) : p.W;
+                    const uint32_t y1 = ((bv + 1u) << shift) < p.H ? ((bv + 1u) << shift) : p.H;
+                    const uint32_t *mb = p.maskbits + (size_t)y * p.mwords;
+                    all = true;
+                    for (uint32_t yy = y0; yy < y1; ++yy) span_any_all(mb, yy * p.W + x0, x1 - x0, any, all);
+                }
+            }
+            // bw is a multiple of 32 and a wave starts at a multiple of 64: each half-wave is one grid word
+            const uint64_t bany = __ballot(any), ball = __ballot(all);
+            if ((lane & 31u) == 0 && t < nb) {
+                const uint32_t rv = t / bw, ru = t - rv * bw;
+                const uint32_t w = gc.off + rv * gc.cws + (ru >> 5);
+                grid[w] = (uint32_t)(bany >> lane);
+                grid[w + (uint32_t)gc.ch * gc.cws] = (uint32_t)(ball >> lane);
+            }
+        }
+    } else {
+        // pass count of each camera on `nsamples` evenly spaced voxels of the slab, kEstPerThread per thread
+        if (blockIdx.x * kBlock * kEstPerThread >= nsamples) return;
+        double X[kEstPerThread], Y[kEstPerThread], Z[kEstPerThread];
+        uint32_t valid = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kEstPerThread; ++k) {
+            const uint32_t sidx = (blockIdx.x * kEstPerThread + k) * kBlock + threadIdx.x;
+            uint32_t ix = 0, iy = 0, izl = 0;
+            if (sidx < nsamples) {
+                valid |= 1u << k;
+                decompose((uint32_t)(((uint64_t)sidx * p.n) / nsamples), p.nx, p.ny, ix, iy, izl);
+            }
+            X[k] = p.xs[ix]; Y[k] = p.ys[iy]; Z[k] = p.zs[p.z0 + izl];
+        }
+        for (uint32_t c = 0; c < p.C; ++c) {
+            uint32_t hits = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < kEstPerThread; ++k) {
+                double u, v;
+                project_point(p.cam[c], X[k], Y[k], Z[k], u, v);
+                const int32_t off = pixel_offset(u, v, p.H, p.W);
+                const bool hit = ((valid >> k) & 1u) && off >= 0 && mask_bit(p.maskbits + (size_t)c * p.mwords, off);
+                hits += (uint32_t)__popcll(__ballot(hit));
+            }
+            if (lane == 0 && hits) atomicAdd(&scratch->est[c], hits);
+        }
+    }
+    const uint32_t est_wgs = (nsamples + kBlock * kEstPerThread - 1) / (kBlock * kEstPerThread);
+    if (!last_workgroup(&scratch->ticket[1], hdr_u32(grid, kHdrGridWgs) + est_wgs, &s_flag)) return;
+    if (threadIdx.x != 0) return;
+    uint32_t order[kMaxCameras], cnt[kMaxCameras];
+    for (uint32_t c = 0; c < kMaxCameras; ++c) {
+        order[c] = c;
+        cnt[c] = (c < p.C && reorder) ? ld_agent(&scratch->est[c]) : 0u;
+        scratch->est[c] = 0;
+    }
+    for (uint32_t a = 1; a < p.C; ++a)                            // stable insertion sort, ascending pass count
+        for (uint32_t b = a; b > 0 && cnt[order[b]] < cnt[order[b - 1]]; --b) {
+            const uint32_t x = order[b]; order[b] = order[b - 1]; order[b - 1] = x;
+        }
+    for (uint32_t c = 0; c < kMaxCameras; ++c) grid[kHdrOrder + c] = order[c];
+}
+
 // ---------------------------------------------------------------- compaction
 // Ordered compaction without a sort: survivors per 64-word group -> exclusive scan (two
 // levels) -> one wave per group expands its words into records.
-__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane)
-{
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(v, d);
-        if (lane >= (uint32_t)d) v += o;
-    }
-    return v;
-}
 
 // For the kernels that do not write groupcnt themselves (fused, generic): one wave per group.
 __global__ __launch_bounds__(kBlock) void k_count_groups(const uint64_t *__restrict__ words, uint64_t nwords,
@@ -1244,15 +1420,6 @@ __global__ __launch_bounds__(kBlock) void k_finish_scan(const uint64_t *__restri
         *total_host = total;
         *busycount = wred[0] + wred[1] + wred[2] + wred[3];
     }
-}
-
-// BGR bytes -> one BGRX dword per pixel, so a colour sample is a single aligned load.
-__global__ __launch_bounds__(kBlock) void k_expand_frame(const uint8_t *__restrict__ bgr, uint32_t *__restrict__ out,
-                                                         uint32_t npix)
-{
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= npix) return;
-    out[i] = (uint32_t)bgr[3 * i] | ((uint32_t)bgr[3 * i + 1] << 8) | ((uint32_t)bgr[3 * i + 2] << 16);
 }
 
 // r-th (0-based) set bit of x; requires r < popcount(x).

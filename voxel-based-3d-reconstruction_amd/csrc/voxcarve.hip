@@ -85,16 +85,25 @@ struct DevBuf {
     size_t cap = 0;     // elements
 };
 
+// One resident frame set.  The uploaded bytes stay on the device (bytes / fbytes), so the derived state (bit masks,
+// BGRX images, block grids, camera order -- all made on the device by k_prep_pack / k_prep_grid, queued in front of
+// the first carve that uses the slot) can be re-derived without another transfer (vc_touch_masks).
 struct Slot {
+    DevBuf<uint8_t> bytes;      // [C][H*W] byte masks as uploaded
+    uint8_t *h_bytes = nullptr; // page-locked staging of the same size: uploads are asynchronous
+    size_t h_bytes_cap = 0;
+    DevBuf<uint8_t> fbytes[VC_MAX_CAMERAS];   // [H*W*3] BGR image of a camera as uploaded
+    uint8_t *h_fbytes[VC_MAX_CAMERAS] = {nullptr};
     DevBuf<uint32_t> bits;      // [C][mwords]
     DevBuf<uint32_t> frames;    // [C][H*W] BGRX, one dword per pixel
-    std::vector<uint8_t> have_frame;
-    bool have_masks = false;
-    DevBuf<uint32_t> grid;      // cropped block grids of all cameras (hierarchical kernels stage them in LDS)
-    GridCam crop[VC_MAX_CAMERAS];
-    uint32_t gshift = 2, grid_words = 0;
-    uint32_t order[VC_MAX_CAMERAS];  // most selective camera first (k_estimate)
-    bool order_valid = false;
+    std::vector<uint8_t> have_frame, frame_dirty;
+    bool have_masks = false;    // byte masks staged
+    bool bits_valid = false;    // bits, BGRX images and the grid plan match the staged bytes
+    bool grids_valid = false;   // block grids and camera order too (they also depend on grid, slab and cameras)
+    DevBuf<uint32_t> grid;      // header + cropped block grids of all cameras (hierarchical kernels stage it in LDS)
+    uint32_t budget_words = 0;  // LDS budget the plan was made for (fixes the dynamic LDS size of the carve launch)
+    hipEvent_t e_up = nullptr, e_read = nullptr, e_emit = nullptr;   // last upload | last read of the bytes | last expansion reading bits / images
+    bool up_pending = false, read_pending = false, emit_pending = false;
 };
 
 // np.linspace(lo, hi, num=n) in float64: y[k] = k*step + lo (two roundings), y[n-1] = hi
@@ -125,7 +134,8 @@ struct StepBuf {
     DevBuf<uint64_t> blocksum, blockoff;     // blockoff[nscan] = total
     DevBuf<uint64_t> records;
     uint64_t *h_total = nullptr;             // pinned
-    hipEvent_t e0 = nullptr, e_first = nullptr, e1 = nullptr, e2 = nullptr, e_scan = nullptr;
+    hipEvent_t e0 = nullptr, e_first = nullptr, e1 = nullptr, e2 = nullptr, e_scan = nullptr, e_prep = nullptr;
+    bool prepped = false;                    // this step queued preparation kernels in front of its carve (e_prep .. e0)
     bool pending = false, used = false;
     EmitParams emit;                         // kept for a re-run after a records regrow
     bool allseen = false, want_vm = false, has_first = false;
@@ -146,6 +156,10 @@ struct vc_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // scan + record expansion of step i, beside the carve of step i+1 on `stream`
+    hipStream_t stream_up = nullptr; // host-to-device copies of masks and images (overlap the carve in flight)
+    DevBuf<PrepScratch> d_prep;      // self-cleaning scratch of the per-frame preparation kernels
+    hipEvent_t ev_h[2] = {nullptr, nullptr};   // around the last mask upload (h2d_ms)
+    bool h2d_pending = false;
     int overlap = 1;                 // (one stream when a communicator is attached: its collectives order everything)
     StepBuf sb[2];
     int head = 0, npending = 0, cur = -1;    // next set to issue into, steps in flight, set holding the fetched result
@@ -166,8 +180,7 @@ struct vc_ctx {
 
     std::vector<Slot> slots;
     uint8_t post_open[VC_MAX_CAMERAS] = {0}, post_close[VC_MAX_CAMERAS] = {0};   // 2x2 open / close per camera
-    DevBuf<uint8_t> d_morph;         // ping-pong image for the post-filter
-    DevBuf<uint8_t> d_stage;         // H2D staging for byte masks
+    DevBuf<uint8_t> d_morph;         // post-filtered byte masks [C][H*W] + one scratch image
 
     DevBuf<int32_t> d_lut;
     DevBuf<uint64_t> d_bbox;         // [C][n_pad/64] per-word pixel boxes (built with the LUT)
@@ -182,11 +195,7 @@ struct vc_ctx {
     int fused_f32box = 1;            // its word boxes from float32 intervals after a float64 rigid transform ...
     int fused_color_table = 0;       // VC_MODE_FUSED: colour the survivors from the colour camera's table (one camera, whole grid)
     int fused_boxes = 1;             // ... or read from boxes reduced once from the exact pixels (no table involved)
-    DevBuf<uint32_t> d_mbbox;        // per camera foreground pixel bounding box (k_mask_bbox)
-    uint32_t *h_mbbox = nullptr;     // pinned, 4 per camera
     bool lut_valid = false;
-    DevBuf<uint32_t> d_est;          // per-camera pass counts of k_estimate
-    uint32_t *h_est = nullptr;       // pinned, VC_MAX_CAMERAS
     // tuning knobs (vc_set_option); defaults are the measured best on MI355X
     bool force_generic = false;      // one-thread-per-voxel kernels only (cross-check path)
     int first_kv = 1;                // dwordx4 loads per lane per chunk in k_lut_first: 1, 2 or 4
@@ -306,54 +315,13 @@ void fill_params(const vc_ctx *ctx, CarveParams &p)
     p.tile_whole = (p.tq != 0 && 64 % p.tq == 0) ? 1u : 0u;
 }
 
-// Block grids of a frame set.  A silhouette covers a few percent of its image, so only the blocks
-// around each camera's foreground are kept (GridCam); what that saves goes into resolution: the
-// finest power-of-two block whose grids of all cameras fit grid_lds_kb (16 KB: room for 8 workgroups
-// per CU, and the hierarchical kernels' LDS fill becomes a non-event).
-
-int build_block_grids(vc_ctx *ctx, Slot &s)
-{
-    const uint32_t C = ctx->C, H = ctx->H, W = ctx->W;
-    VC_TRY(ensure(ctx, ctx->d_mbbox, 4 * VC_MAX_CAMERAS));
-    if (!ctx->h_mbbox)
-        VC_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_mbbox), sizeof(uint32_t) * 4 * VC_MAX_CAMERAS, hipHostMallocDefault));
-    hipLaunchKernelGGL(k_mask_bbox, dim3(C), dim3(kBlock), 0, ctx->stream, s.bits.ptr, ctx->mwords, H, W, ctx->d_mbbox.ptr);
-    VC_HIP(ctx, hipGetLastError());
-    VC_HIP(ctx, hipMemcpyAsync(ctx->h_mbbox, ctx->d_mbbox.ptr, sizeof(uint32_t) * 4 * C, hipMemcpyDeviceToHost, ctx->stream));
-    VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    uint32_t total = 0, maxblocks = 0;
-    for (s.gshift = (uint32_t)ctx->grid_min_shift; s.gshift < 15; ++s.gshift) {
-        total = kGridHeader; maxblocks = 0;
-        for (uint32_t c = 0; c < C; ++c) {
-            GridCam &g = s.crop[c];
-            const uint32_t *b = ctx->h_mbbox + 4 * c;            // u_min, u_max, v_min, v_max
-            g.off = total; g.w_lo = g.v_lo = g.cws = g.ch = 0;
-            if (b[0] > b[1]) continue;                           // no foreground in this camera
-            g.w_lo = (uint16_t)((b[0] >> s.gshift) >> 5);
-            g.cws = (uint16_t)(((b[1] >> s.gshift) >> 5) - g.w_lo + 1);
-            g.v_lo = (uint16_t)(b[2] >> s.gshift);
-            g.ch = (uint16_t)((b[3] >> s.gshift) - g.v_lo + 1);
-            total += 2u * g.cws * g.ch;
-            const uint32_t blocks = 32u * g.cws * g.ch;
-            maxblocks = blocks > maxblocks ? blocks : maxblocks;
-        }
-        // W <= 65535, H <= 32767: at 2^14-pixel blocks every grid is a few words, so the loop ends here at the latest
-        if ((size_t)total * sizeof(uint32_t) <= (size_t)ctx->grid_lds_kb * 1024 || s.gshift == 14) break;
-    }
-    s.grid_words = total;
-    VC_TRY(ensure(ctx, s.grid, (size_t)total + 4));               // + padding: kernels copy it 16 bytes at a time
-    VC_HIP(ctx, hipMemsetAsync(s.grid.ptr, 0, ((size_t)total + 4) * sizeof(uint32_t), ctx->stream));
-    if (maxblocks) {
-        GridBuild p;
-        memset(&p, 0, sizeof p);
-        p.H = H; p.W = W; p.mwords = ctx->mwords; p.gshift = s.gshift;
-        memcpy(p.crop, s.crop, sizeof(GridCam) * C);
-        hipLaunchKernelGGL(k_blockgrid, dim3((maxblocks + kBlock - 1) / kBlock, C), dim3(kBlock), 0, ctx->stream, s.bits.ptr,
-                           s.grid.ptr, p);
-        VC_HIP(ctx, hipGetLastError());
-    }
-    return VC_OK;
-}
+constexpr int VC_MAX_RANKS = 64;
+constexpr uint32_t kBusyListMinGroups = 16384;   // below 64 M voxels a wave per group is as fast and one launch shorter
+constexpr uint32_t kMaxScanBlocks = 1024;  // 2^32 voxels / 4096 per group / 1024 groups per scan block
+constexpr int kSub = 4;                    // 64-voxel sub-chunks per wavefront chunk (fused kernel)
+constexpr size_t kLdsBytes = 160 * 1024;   // LDS per CU on gfx950
+constexpr size_t kMaxFirstLds = 64 * 1024; // static limit of one workgroup's dynamic LDS without opt-in
+constexpr uint32_t kEstimateSamples = 1u << 16;
 
 int slot_at(vc_ctx *ctx, uint32_t slot, Slot **out)
 {
@@ -361,13 +329,109 @@ int slot_at(vc_ctx *ctx, uint32_t slot, Slot **out)
     if (slot >= 64) return fail(ctx, VC_ERR_ARG, "slot %u out of range (max 64 resident frame sets)", slot);
     if (slot >= ctx->slots.size()) ctx->slots.resize(slot + 1);
     Slot &s = ctx->slots[slot];
-    if (s.have_frame.size() != ctx->C) s.have_frame.assign(ctx->C, 0);
+    if (s.have_frame.size() != ctx->C) { s.have_frame.assign(ctx->C, 0); s.frame_dirty.assign(ctx->C, 0); }
+    if (!s.e_up) {
+        VC_HIP(ctx, hipEventCreateWithFlags(&s.e_up, hipEventDisableTiming));
+        VC_HIP(ctx, hipEventCreateWithFlags(&s.e_read, hipEventDisableTiming));
+        VC_HIP(ctx, hipEventCreateWithFlags(&s.e_emit, hipEventDisableTiming));
+    }
     *out = &s;
     return VC_OK;
 }
 
-uint32_t grid_for(uint64_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
+void release_slot(Slot &s)
+{
+    release(s.bytes); release(s.bits); release(s.frames); release(s.grid);
+    for (int c = 0; c < VC_MAX_CAMERAS; ++c) {
+        release(s.fbytes[c]);
+        if (s.h_fbytes[c]) { (void)hipHostFree(s.h_fbytes[c]); s.h_fbytes[c] = nullptr; }
+    }
+    if (s.h_bytes) { (void)hipHostFree(s.h_bytes); s.h_bytes = nullptr; s.h_bytes_cap = 0; }
+    s.have_masks = s.bits_valid = s.grids_valid = false;
+    s.have_frame.clear(); s.frame_dirty.clear();
+}
 
+uint32_t grid_for(uint64_t n);
+
+// Queues, on the carve stream, whatever the slot's derived state is missing: bit masks + BGRX images + grid plan
+// (k_prep_pack, after the optional 2x2 post-filter), and for the chunked / hierarchical kernels the block grids and
+// the camera order (k_prep_grid).  No host synchronisation: the kernels leave their results in the slot's header.
+int ensure_prepared(vc_ctx *ctx, Slot &s, bool want_grids, const CarveParams *cp)
+{
+    const uint32_t C = ctx->C;
+    const size_t HW = (size_t)ctx->H * ctx->W;
+    if (!ctx->d_prep.ptr) {
+        VC_TRY(ensure(ctx, ctx->d_prep, 1));
+        PrepScratch init;
+        memset(&init, 0, sizeof init);
+        for (uint32_t c = 0; c < kMaxCameras; ++c) { init.bbox[c][0] = 0xffffffffu; init.bbox[c][2] = 0xffffffffu; }
+        VC_HIP(ctx, hipMemcpy(ctx->d_prep.ptr, &init, sizeof init, hipMemcpyHostToDevice));
+    }
+    if (!s.bits_valid) {
+        if (s.up_pending) VC_HIP(ctx, hipStreamWaitEvent(ctx->stream, s.e_up, 0));
+        if (s.emit_pending) { VC_HIP(ctx, hipStreamWaitEvent(ctx->stream, s.e_emit, 0)); s.emit_pending = false; }
+        VC_TRY(ensure(ctx, s.bits, (size_t)ctx->mwords * C));
+        const uint32_t budget = (uint32_t)ctx->grid_lds_kb * 256u;            // u32 words
+        VC_TRY(ensure(ctx, s.grid, (size_t)(budget > 256u ? budget : 256u) + 8));   // + padding: kernels copy it 16 bytes at a time
+        s.budget_words = budget;
+        PrepParams pp;
+        memset(&pp, 0, sizeof pp);
+        for (uint32_t c = 0; c < C; ++c) {
+            pp.src[c] = s.bytes.ptr + HW * c;
+            if (!ctx->post_open[c] && !ctx->post_close[c]) continue;
+            // MORPH_OPEN = erode, dilate; MORPH_CLOSE = dilate, erode (opening first when both are set); the uploaded
+            // bytes stay as they are, the filtered image of camera c goes to d_morph[c]
+            VC_TRY(ensure(ctx, ctx->d_morph, HW * (C + 1)));
+            const uint8_t *img = s.bytes.ptr + HW * c;
+            uint8_t *fin = ctx->d_morph.ptr + HW * c, *tmp = ctx->d_morph.ptr + HW * C;
+            const dim3 mg(grid_for(HW)), mb(kBlock);
+            if (ctx->post_open[c]) {
+                hipLaunchKernelGGL((k_morph2x2<false>), mg, mb, 0, ctx->stream, img, tmp, ctx->H, ctx->W);
+                hipLaunchKernelGGL((k_morph2x2<true>), mg, mb, 0, ctx->stream, (const uint8_t *)tmp, fin, ctx->H, ctx->W);
+                img = fin;
+            }
+            if (ctx->post_close[c]) {
+                hipLaunchKernelGGL((k_morph2x2<true>), mg, mb, 0, ctx->stream, img, tmp, ctx->H, ctx->W);
+                hipLaunchKernelGGL((k_morph2x2<false>), mg, mb, 0, ctx->stream, (const uint8_t *)tmp, fin, ctx->H, ctx->W);
+            }
+            VC_HIP(ctx, hipGetLastError());
+            pp.src[c] = fin;
+        }
+        for (uint32_t c = 0; c < C; ++c) {
+            if (!s.frame_dirty[c]) continue;
+            pp.fsrc[pp.nframes] = s.fbytes[c].ptr;
+            pp.fdst[pp.nframes] = s.frames.ptr + HW * c;
+            pp.nframes++;
+            s.frame_dirty[c] = 0;
+        }
+        pp.bits = s.bits.ptr; pp.grid = s.grid.ptr; pp.scratch = ctx->d_prep.ptr;
+        pp.C = C; pp.H = ctx->H; pp.W = ctx->W; pp.HW = (uint32_t)HW; pp.mwords = ctx->mwords;
+        pp.min_shift = (uint32_t)ctx->grid_min_shift; pp.budget_words = budget;
+        const uint32_t pw = (ctx->mwords + kBlock - 1) / kBlock, fw = (uint32_t)((HW + 4 * kBlock - 1) / (4 * kBlock));
+        hipLaunchKernelGGL(k_prep_pack, dim3(C * pw + pp.nframes * fw), dim3(kBlock), 0, ctx->stream, pp);
+        VC_HIP(ctx, hipGetLastError());
+        VC_HIP(ctx, hipEventRecord(s.e_read, ctx->stream));
+        s.read_pending = true;
+        s.bits_valid = true;
+        s.grids_valid = false;
+    }
+    if (want_grids && !s.grids_valid) {
+        CarveParams p = *cp;
+        p.maskbits = s.bits.ptr;
+        const uint64_t n = p.n;
+        const uint32_t ns = (uint32_t)(n < kEstimateSamples ? n : kEstimateSamples);
+        const uint32_t est_wgs = (ns + kBlock * kEstPerThread - 1) / (kBlock * kEstPerThread);
+        // a camera's grids hold at most 16 blocks per budgeted word
+        const uint32_t grid_wgs = (16u * (s.budget_words > 256u ? s.budget_words : 256u) + kBlock - 1) / kBlock;
+        hipLaunchKernelGGL(k_prep_grid, dim3(grid_wgs > est_wgs ? grid_wgs : est_wgs, C + 1), dim3(kBlock), 0, ctx->stream, p,
+                           s.grid.ptr, ctx->d_prep.ptr, ns, (uint32_t)(ctx->reorder ? 1 : 0));
+        VC_HIP(ctx, hipGetLastError());
+        s.grids_valid = true;
+    }
+    return VC_OK;
+}
+
+uint32_t grid_for(uint64_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
 
 constexpr int kEmitBatch = 4;              // survivors per lane in flight together in k_emit_words
 
@@ -398,13 +462,6 @@ int launch_emit(vc_ctx *ctx, StepBuf &sb, hipStream_t st)
     return VC_OK;
 }
 
-constexpr int VC_MAX_RANKS = 64;
-constexpr uint32_t kBusyListMinGroups = 16384;   // below 64 M voxels a wave per group is as fast and one launch shorter
-constexpr uint32_t kMaxScanBlocks = 1024;  // 2^32 voxels / 4096 per group / 1024 groups per scan block
-constexpr int kSub = 4;                    // 64-voxel sub-chunks per wavefront chunk (fused kernel)
-constexpr size_t kLdsBytes = 160 * 1024;   // LDS per CU on gfx950
-constexpr size_t kMaxFirstLds = 64 * 1024; // static limit of one workgroup's dynamic LDS without opt-in
-constexpr uint32_t kEstimateSamples = 1u << 16;
 
 // counts -> exclusive offsets (two levels) on the context's stream; the total also lands in *total_host
 int scan_counts(vc_ctx *ctx, hipStream_t st, const uint32_t *cnt, uint32_t ngroups, uint32_t *off, uint64_t *bsum, uint64_t *boff,
@@ -581,6 +638,11 @@ int enqueue_expand(vc_ctx *ctx, hipStream_t st, const uint64_t *d_entries, uint6
     else if (cur.allseen) hipLaunchKernelGGL((k_emit_lanes<false, true, 4, true>), grid, block, 0, st, e);
     else hipLaunchKernelGGL((k_emit_lanes<false, false, 4, true>), grid, block, 0, st, e);
     VC_HIP(ctx, hipGetLastError());
+    if (cur.color_cam >= 0 && st != ctx->stream) {               // reads the slot's bits / images beside the carve stream
+        Slot &s = ctx->slots[cur.slot];
+        VC_HIP(ctx, hipEventRecord(s.e_emit, st));
+        s.emit_pending = true;
+    }
     return VC_OK;
 }
 
@@ -620,6 +682,8 @@ int vc_create(int device, vc_ctx **out)
     memset(&ctx->tm, 0, sizeof ctx->tm);
     hipError_t e1 = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e1 == hipSuccess) e1 = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
+    if (e1 == hipSuccess) e1 = hipStreamCreateWithFlags(&ctx->stream_up, hipStreamNonBlocking);
+    for (int k = 0; k < 2 && e1 == hipSuccess; ++k) e1 = hipEventCreate(&ctx->ev_h[k]);
     for (int k = 0; k < 2 && e1 == hipSuccess; ++k) {
         StepBuf &b = ctx->sb[k];
         e1 = hipEventCreate(&b.e0);
@@ -627,11 +691,11 @@ int vc_create(int device, vc_ctx **out)
         if (e1 == hipSuccess) e1 = hipEventCreate(&b.e1);
         if (e1 == hipSuccess) e1 = hipEventCreate(&b.e2);
         if (e1 == hipSuccess) e1 = hipEventCreate(&b.e_scan);
+            if (e1 == hipSuccess) e1 = hipEventCreate(&b.e_prep);
         if (e1 == hipSuccess) e1 = hipHostMalloc(reinterpret_cast<void **>(&b.h_total), sizeof(uint64_t), hipHostMallocDefault);
     }
     for (int i = 0; i < 4 && e1 == hipSuccess; ++i) e1 = hipEventCreate(&ctx->ev[i]);
     if (e1 == hipSuccess) e1 = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_total), sizeof(uint64_t), hipHostMallocDefault);
-    if (e1 == hipSuccess) e1 = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_est), sizeof(uint32_t) * VC_MAX_CAMERAS, hipHostMallocDefault);
     const char *fg = getenv("VOXCARVE_FORCE_GENERIC");
     ctx->force_generic = fg && fg[0] == '1';
     if (e1 != hipSuccess) {
@@ -649,9 +713,17 @@ int vc_destroy(vc_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+    if (ctx->stream_up) (void)hipStreamSynchronize(ctx->stream_up);
     if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
-    for (Slot &s : ctx->slots) { release(s.bits); release(s.frames); release(s.grid); }
-    release(ctx->d_axes); release(ctx->d_stage); release(ctx->d_morph); release(ctx->d_lut); release(ctx->d_bbox); release(ctx->d_lut_tile); release(ctx->d_tbox);
+    for (Slot &s : ctx->slots) {
+        release_slot(s);
+        if (s.e_up) (void)hipEventDestroy(s.e_up);
+        if (s.e_read) (void)hipEventDestroy(s.e_read);
+        if (s.e_emit) (void)hipEventDestroy(s.e_emit);
+    }
+    release(ctx->d_prep);
+    for (int k = 0; k < 2; ++k) if (ctx->ev_h[k]) (void)hipEventDestroy(ctx->ev_h[k]);
+    release(ctx->d_axes); release(ctx->d_morph); release(ctx->d_lut); release(ctx->d_bbox); release(ctx->d_lut_tile); release(ctx->d_tbox);
     for (StepBuf &b : ctx->sb) {
         release(b.words); release(b.groupcnt); release(b.groupoff); release(b.blocksum); release(b.blockoff); release(b.records);
         release(b.ent); release(b.mine); release(b.counts);
@@ -663,6 +735,7 @@ int vc_destroy(vc_ctx *ctx)
         if (b.e1) (void)hipEventDestroy(b.e1);
         if (b.e2) (void)hipEventDestroy(b.e2);
         if (b.e_scan) (void)hipEventDestroy(b.e_scan);
+        if (b.e_prep) (void)hipEventDestroy(b.e_prep);
     }
     release(ctx->d_viewmask); release(ctx->d_scratch); release(ctx->d_counts); release(ctx->d_gathered);
     release(ctx->d_ent_all); release(ctx->d_xcnt); release(ctx->d_xoff); release(ctx->d_xbsum);
@@ -670,12 +743,10 @@ int vc_destroy(vc_ctx *ctx)
     release(ctx->d_ycnt); release(ctx->d_yoff); release(ctx->d_ybsum); release(ctx->d_yboff);
     if (ctx->h_xtotal) (void)hipHostFree(ctx->h_xtotal);
     if (ctx->h_total) (void)hipHostFree(ctx->h_total);
-    if (ctx->h_est) (void)hipHostFree(ctx->h_est);
-    release(ctx->d_est); release(ctx->d_mbbox);
-    if (ctx->h_mbbox) (void)hipHostFree(ctx->h_mbbox);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
     for (int i = 0; i < 4; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->stream_up) (void)hipStreamDestroy(ctx->stream_up);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return VC_OK;
@@ -688,6 +759,7 @@ int vc_synchronize(vc_ctx *ctx)
     if (!ctx) return VC_ERR_ARG;
     VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     VC_HIP(ctx, hipStreamSynchronize(ctx->stream2));
+    VC_HIP(ctx, hipStreamSynchronize(ctx->stream_up));
     return finish_gather(ctx);
 }
 
@@ -711,6 +783,7 @@ int vc_set_grid(vc_ctx *ctx, uint32_t nx, uint32_t ny, uint32_t nz, const double
     VC_HIP(ctx, hipMemcpyAsync(ctx->d_axes.ptr + nx + ny, ctx->zs.data(), sizeof(double) * nz, hipMemcpyHostToDevice, ctx->stream));
     VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->have_grid = true;
+    for (Slot &sl : ctx->slots) sl.grids_valid = false;       // the camera order was sampled on the old geometry
     ctx->lut_valid = false; ctx->bbox_valid = false; ctx->tbox_valid = false; ctx->carved = false; ctx->gathered = false; ctx->viewmask_valid = false;
     ctx->lut_color_cam = -1; ctx->packed = false;
     return VC_OK;
@@ -723,6 +796,7 @@ int vc_set_slab(vc_ctx *ctx, uint32_t z0, uint32_t z1)
     if (!ctx->have_grid) return fail(ctx, VC_ERR_ARG, "vc_set_grid must precede vc_set_slab");
     if (z0 > z1 || z1 > ctx->nz) return fail(ctx, VC_ERR_ARG, "slab [%u,%u) outside [0,%u]", z0, z1, ctx->nz);
     ctx->z0 = z0; ctx->z1 = z1;
+    for (Slot &sl : ctx->slots) sl.grids_valid = false;
     ctx->lut_valid = false; ctx->bbox_valid = false; ctx->tbox_valid = false; ctx->carved = false; ctx->gathered = false; ctx->viewmask_valid = false;
     ctx->packed = false;
     return VC_OK;
@@ -759,12 +833,41 @@ int vc_set_cameras(vc_ctx *ctx, uint32_t C, const double *K9, const double *dist
     ctx->C = C; ctx->H = H; ctx->W = W;
     ctx->mwords = (uint32_t)(((uint64_t)H * W + 31) / 32);
     ctx->have_cams = true;
+    (void)hipSetDevice(ctx->device);
     if (reshaped) {
-        (void)hipSetDevice(ctx->device);
-        for (Slot &s : ctx->slots) { release(s.bits); release(s.frames); release(s.grid); s.have_masks = false; s.have_frame.clear(); }
+        VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        VC_HIP(ctx, hipStreamSynchronize(ctx->stream2));
+        VC_HIP(ctx, hipStreamSynchronize(ctx->stream_up));
+        for (Slot &s : ctx->slots) release_slot(s);
     }
+    for (Slot &sl : ctx->slots) sl.grids_valid = false;
     ctx->lut_valid = false; ctx->bbox_valid = false; ctx->tbox_valid = false; ctx->carved = false; ctx->gathered = false; ctx->viewmask_valid = false;
     ctx->lut_color_cam = -1; ctx->packed = false;
+    return VC_OK;
+}
+
+// Host -> device copy of `bytes` into dst through the page-locked buffer *h_stage (grown on demand), on the upload
+// stream.  The host only ever waits for ITS OWN previous copy out of that staging buffer; the copy itself waits (on
+// the device) for the kernels that still read the bytes it replaces.
+static int stage_upload(vc_ctx *ctx, Slot &s, uint8_t **h_stage, size_t *h_cap, uint8_t *dst, const uint8_t *src, size_t bytes, bool timed)
+{
+    if (s.up_pending) { VC_HIP(ctx, hipEventSynchronize(s.e_up)); s.up_pending = false; }
+    if (!*h_stage || (h_cap && *h_cap < bytes)) {
+        if (*h_stage) VC_HIP(ctx, hipHostFree(*h_stage));
+        *h_stage = nullptr;
+        VC_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(h_stage), bytes, hipHostMallocDefault));
+        if (h_cap) *h_cap = bytes;
+    }
+    memcpy(*h_stage, src, bytes);
+    if (s.read_pending) { VC_HIP(ctx, hipStreamWaitEvent(ctx->stream_up, s.e_read, 0)); s.read_pending = false; }
+    if (timed) {
+        if (ctx->h2d_pending) { (void)hipEventSynchronize(ctx->ev_h[1]); (void)hipEventElapsedTime(&ctx->tm.h2d_ms, ctx->ev_h[0], ctx->ev_h[1]); }
+        VC_HIP(ctx, hipEventRecord(ctx->ev_h[0], ctx->stream_up));
+    }
+    VC_HIP(ctx, hipMemcpyAsync(dst, *h_stage, bytes, hipMemcpyHostToDevice, ctx->stream_up));
+    if (timed) { VC_HIP(ctx, hipEventRecord(ctx->ev_h[1], ctx->stream_up)); ctx->h2d_pending = true; }
+    VC_HIP(ctx, hipEventRecord(s.e_up, ctx->stream_up));
+    s.up_pending = true;
     return VC_OK;
 }
 
@@ -774,38 +877,23 @@ int vc_upload_masks(vc_ctx *ctx, uint32_t slot, const uint8_t *masks)
     Slot *s = nullptr;
     VC_TRY(slot_at(ctx, slot, &s));
     VC_HIP(ctx, hipSetDevice(ctx->device));
-    VC_HIP(ctx, hipStreamSynchronize(ctx->stream2));      // an expansion in flight may still read this slot's mask bits
     const size_t HW = (size_t)ctx->H * ctx->W;
-    VC_TRY(ensure(ctx, ctx->d_stage, HW * (ctx->C > 3 ? ctx->C : 3) + 64));
-    VC_TRY(ensure(ctx, s->bits, (size_t)ctx->mwords * ctx->C));
-    VC_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    VC_HIP(ctx, hipMemcpyAsync(ctx->d_stage.ptr, masks, HW * ctx->C, hipMemcpyHostToDevice, ctx->stream));
-    for (uint32_t c = 0; c < ctx->C; ++c) {
-        if (!ctx->post_open[c] && !ctx->post_close[c]) continue;
-        // MORPH_OPEN = erode, dilate; MORPH_CLOSE = dilate, erode (opening first when both are set)
-        VC_TRY(ensure(ctx, ctx->d_morph, HW));
-        uint8_t *img = ctx->d_stage.ptr + HW * c, *tmp = ctx->d_morph.ptr;
-        const dim3 mg(grid_for(HW)), mb(kBlock);
-        if (ctx->post_open[c]) {
-            hipLaunchKernelGGL((k_morph2x2<false>), mg, mb, 0, ctx->stream, img, tmp, ctx->H, ctx->W);
-            hipLaunchKernelGGL((k_morph2x2<true>), mg, mb, 0, ctx->stream, tmp, img, ctx->H, ctx->W);
-        }
-        if (ctx->post_close[c]) {
-            hipLaunchKernelGGL((k_morph2x2<true>), mg, mb, 0, ctx->stream, img, tmp, ctx->H, ctx->W);
-            hipLaunchKernelGGL((k_morph2x2<false>), mg, mb, 0, ctx->stream, tmp, img, ctx->H, ctx->W);
-        }
-        VC_HIP(ctx, hipGetLastError());
-    }
-    dim3 grid((ctx->mwords + kBlock - 1) / kBlock, ctx->C);
-    hipLaunchKernelGGL(k_pack_masks, grid, dim3(kBlock), 0, ctx->stream, ctx->d_stage.ptr, s->bits.ptr,
-                       ctx->C, (uint32_t)HW, ctx->mwords);
-    VC_HIP(ctx, hipGetLastError());
-    VC_TRY(build_block_grids(ctx, *s));
-    VC_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-    VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.h2d_ms, ctx->ev[0], ctx->ev[1]));
+    VC_TRY(ensure(ctx, s->bytes, HW * ctx->C + 64));
+    VC_TRY(stage_upload(ctx, *s, &s->h_bytes, &s->h_bytes_cap, s->bytes.ptr, masks, HW * ctx->C, true));
     s->have_masks = true;
-    s->order_valid = false;
+    s->bits_valid = false;           // the next carve on this slot re-derives bits, grids and camera order on the device
+    s->grids_valid = false;
+    return VC_OK;
+}
+
+int vc_touch_masks(vc_ctx *ctx, uint32_t slot)
+{
+    if (!ctx) return VC_ERR_ARG;
+    if (slot >= ctx->slots.size() || !ctx->slots[slot].have_masks) return fail(ctx, VC_ERR_ARG, "no masks uploaded in slot %u", slot);
+    Slot &s = ctx->slots[slot];
+    s.bits_valid = false;
+    s.grids_valid = false;
+    for (uint32_t c = 0; c < ctx->C; ++c) if (s.have_frame[c]) s.frame_dirty[c] = 1;
     return VC_OK;
 }
 
@@ -826,6 +914,8 @@ int vc_fetch_mask(vc_ctx *ctx, uint32_t slot, uint32_t cam, uint8_t *out)
     if (slot >= ctx->slots.size() || !ctx->slots[slot].have_masks) return fail(ctx, VC_ERR_ARG, "no masks uploaded in slot %u", slot);
     if (cam >= ctx->C) return fail(ctx, VC_ERR_ARG, "camera %u not in [0,%u)", cam, ctx->C);
     VC_HIP(ctx, hipSetDevice(ctx->device));
+    VC_TRY(ensure_prepared(ctx, ctx->slots[slot], false, nullptr));
+    VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     std::vector<uint32_t> bits(ctx->mwords);
     VC_HIP(ctx, hipMemcpy(bits.data(), ctx->slots[slot].bits.ptr + (size_t)cam * ctx->mwords, sizeof(uint32_t) * ctx->mwords,
                           hipMemcpyDeviceToHost));
@@ -841,16 +931,13 @@ int vc_upload_frame(vc_ctx *ctx, uint32_t slot, uint32_t cam, const uint8_t *bgr
     VC_TRY(slot_at(ctx, slot, &s));
     if (cam >= ctx->C) return fail(ctx, VC_ERR_ARG, "camera %u not in [0,%u)", cam, ctx->C);
     VC_HIP(ctx, hipSetDevice(ctx->device));
-    VC_HIP(ctx, hipStreamSynchronize(ctx->stream2));      // an expansion in flight may still read this slot's frame
     const size_t npix = (size_t)ctx->H * ctx->W;
     VC_TRY(ensure(ctx, s->frames, npix * ctx->C));
-    VC_TRY(ensure(ctx, ctx->d_stage, npix * (ctx->C > 3 ? ctx->C : 3) + 64));
-    VC_HIP(ctx, hipMemcpyAsync(ctx->d_stage.ptr, bgr, npix * 3, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_expand_frame, dim3(grid_for(npix)), dim3(kBlock), 0, ctx->stream, ctx->d_stage.ptr,
-                       s->frames.ptr + npix * cam, (uint32_t)npix);
-    VC_HIP(ctx, hipGetLastError());
-    VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    VC_TRY(ensure(ctx, s->fbytes[cam], npix * 3 + 64));
+    VC_TRY(stage_upload(ctx, *s, &s->h_fbytes[cam], nullptr, s->fbytes[cam].ptr, bgr, npix * 3, false));
     s->have_frame[cam] = 1;
+    s->frame_dirty[cam] = 1;
+    s->bits_valid = false;           // the BGRX expansion rides in the same launch as the bit-packing
     return VC_OK;
 }
 
@@ -935,9 +1022,13 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     const bool want_vm = (flags & VC_FLAG_VIEWMASK) != 0;
     ctx->gathered = false;
     ctx->tm.voxels = n;
+    if (ctx->head == ctx->cur) {
+        // this step is queued into the buffers that hold the result the vc_fetch_* functions read: it is gone from here on
+        ctx->carved = false; ctx->viewmask_valid = false; ctx->packed = false;
+    }
     StepBuf &sb = ctx->sb[ctx->head];
     sb.n = n; sb.survivors = 0; sb.want_vm = want_vm; sb.has_first = false;
-    sb.allseen = min_views >= ctx->C;
+    sb.allseen = min_views == ctx->C;
     sb.no_records = (flags & VC_FLAG_NO_RECORDS) != 0;
     sb.sparse_words = false;
     sb.mode = mode; sb.color_cam = color_cam; sb.slot = slot;
@@ -965,42 +1056,30 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     VC_TRY(ensure(ctx, sb.groupoff, ngroups));
     VC_TRY(ensure(ctx, sb.blocksum, kMaxScanBlocks));
     VC_TRY(ensure(ctx, sb.blockoff, kMaxScanBlocks + 1));
-    VC_TRY(ensure(ctx, ctx->d_est, VC_MAX_CAMERAS));
     if (want_vm) VC_TRY(ensure(ctx, ctx->d_viewmask, n));
     if (!sb.records.ptr && !sb.no_records) VC_TRY(ensure(ctx, sb.records, (size_t)(n / 16 + 1024)));
 
     CarveParams p;
     fill_params(ctx, p);
-    p.maskbits = s.bits.ptr;
     p.lut = ctx->d_lut.ptr;
-    p.blockgrid = s.grid.ptr;
-    p.gshift = s.gshift; p.grid_words = s.grid_words;
     p.words = sb.words.ptr;
     p.groupcnt = sb.groupcnt.ptr;
     p.viewmask = ctx->d_viewmask.ptr;
     p.min_views = min_views;
 
-    // The chunked kernels cover the reference's case (seen by ALL cameras); the
-    // one-thread-per-voxel kernels cover thresholds below C and the camera bitmask.
-    bool fast = !ctx->force_generic && !want_vm && min_views >= ctx->C;
+    // The chunked kernels cover the reference's case (seen by ALL cameras); the one-thread-per-voxel kernels cover
+    // thresholds below C, the camera bitmask, and thresholds above C (no voxel can be seen by more cameras than
+    // there are: the reference's sum(views.values()) >= views_threshold is never true, the result is empty).
+    bool fast = !ctx->force_generic && !want_vm && min_views == ctx->C;
     // k_lut_first keeps one camera's mask bits in LDS; larger masks take the generic kernel.
     if (mode == VC_MODE_LUT && !ctx->lut_hier && (size_t)ctx->mwords * sizeof(uint32_t) > kMaxFirstLds) fast = false;
-    if (fast && !s.order_valid) {
-        // Most selective camera first: pass counts on a strided sample of the slab.
-        VC_HIP(ctx, hipMemsetAsync(ctx->d_est.ptr, 0, sizeof(uint32_t) * VC_MAX_CAMERAS, ctx->stream));
-        const uint32_t ns = (uint32_t)(n < kEstimateSamples ? n : kEstimateSamples);
-        hipLaunchKernelGGL(k_estimate, dim3(grid_for(ns)), dim3(kBlock), 0, ctx->stream, p, ctx->d_est.ptr, ns);
-        VC_HIP(ctx, hipGetLastError());
-        VC_HIP(ctx, hipMemcpyAsync(ctx->h_est, ctx->d_est.ptr, sizeof(uint32_t) * ctx->C, hipMemcpyDeviceToHost, ctx->stream));
-        VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        for (uint32_t c = 0; c < ctx->C; ++c) s.order[c] = c;
-        for (uint32_t a = 1; a < ctx->C; ++a)             // stable insertion sort, ascending pass count
-            for (uint32_t b = a; b > 0 && ctx->h_est[s.order[b]] < ctx->h_est[s.order[b - 1]]; --b) {
-                const uint32_t t = s.order[b]; s.order[b] = s.order[b - 1]; s.order[b - 1] = t;
-            }
-        s.order_valid = true;
-    }
-    for (uint32_t c = 0; c < ctx->C; ++c) p.order[c] = (fast && ctx->reorder) ? s.order[c] : c;
+    // per-frame preparation, on the device, in front of the carve (nothing to do when the slot has been used before)
+    sb.prepped = !s.bits_valid || (fast && !s.grids_valid);
+    if (sb.prepped) VC_HIP(ctx, hipEventRecord(sb.e_prep, ctx->stream));
+    VC_TRY(ensure_prepared(ctx, s, fast, &p));
+    p.maskbits = s.bits.ptr;
+    p.blockgrid = s.grid.ptr;
+    const size_t grid_lds = ((size_t)(s.budget_words > 256u ? s.budget_words : 256u) + 8) * sizeof(uint32_t);
 
     VC_HIP(ctx, hipEventRecord(sb.e0, ctx->stream));
     const dim3 block(kBlock);
@@ -1011,7 +1090,7 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
         const dim3 grid((uint32_t)(want < gmax ? want : gmax));
         if (mode == VC_MODE_LUT && ctx->lut_hier) {
             // one launch: word-level rejection by pixel box x foreground-block grid, exact test for the rest
-            const size_t lds = ((size_t)s.grid_words + 4) * sizeof(uint32_t);
+            const size_t lds = grid_lds;
             const uint64_t groups = p.n_pad / 4096;
             const uint64_t rwant = (groups + 3) / 4;
             const uint64_t rmax = 256ull * (uint64_t)ctx->hier_blocks_per_cu;
@@ -1053,7 +1132,7 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
             else hipLaunchKernelGGL((k_lut_refine<16, false, false>), rgrid, block, 0, ctx->stream, p);
         }
         else if (ctx->ny % 64 == 0 && ctx->fused_hier) {
-            const size_t lds = ((size_t)s.grid_words + 4) * sizeof(uint32_t);
+            const size_t lds = grid_lds;
             const uint64_t groups = p.n_pad / 4096;
             const uint64_t rwant = (groups + 3) / 4;
             const uint64_t rmax = 256ull * (uint64_t)ctx->hier_blocks_per_cu;
@@ -1158,7 +1237,10 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
         VC_HIP(ctx, hipEventRecord(sb.e_scan, ctx->stream));
         VC_HIP(ctx, hipStreamWaitEvent(s3, sb.e_scan, 0));
     }
-    if (!sb.no_records) VC_TRY(launch_emit(ctx, sb, s3));
+    if (!sb.no_records) {
+        VC_TRY(launch_emit(ctx, sb, s3));
+        if (s3 != ctx->stream) { VC_HIP(ctx, hipEventRecord(s.e_emit, s3)); s.emit_pending = true; }   // reads the slot's bits / images
+    }
     if (auto_exchange) {
         VC_TRY(enqueue_pack(ctx, sb));
         VC_TRY(enqueue_counts_exchange(ctx, sb));
@@ -1204,6 +1286,12 @@ int vc_carve_end(vc_ctx *ctx, uint64_t *n_out)
         ctx->tm.carve_ms_sum += ms;
         ctx->tm.carve_launches += 1;
         VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.compact_ms, sb.e1, sb.e2));
+        ctx->tm.prep_ms = 0;
+        if (sb.prepped) {
+            VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.prep_ms, sb.e_prep, sb.e0));
+            ctx->tm.prep_ms_sum += ctx->tm.prep_ms;
+            ctx->tm.preps += 1;
+        }
     } else {
         if (sb.counts_exchanged) VC_HIP(ctx, hipEventSynchronize(sb.e2));
         sb.survivors = 0;
@@ -1342,6 +1430,10 @@ int vc_timing(vc_ctx *ctx, vc_timing_t *out)
 {
     if (!ctx || !out) return VC_ERR_ARG;
     VC_TRY(finish_gather(ctx));
+    if (ctx->h2d_pending && hipEventQuery(ctx->ev_h[1]) == hipSuccess) {
+        (void)hipEventElapsedTime(&ctx->tm.h2d_ms, ctx->ev_h[0], ctx->ev_h[1]);
+        ctx->h2d_pending = false;
+    }
     *out = ctx->tm;
     return VC_OK;
 }
@@ -1354,6 +1446,8 @@ int vc_timing_reset(vc_ctx *ctx)
     ctx->tm.first_ms_sum = 0;
     ctx->tm.gather_ms_sum = 0;
     ctx->tm.gathers = 0;
+    ctx->tm.prep_ms_sum = 0;
+    ctx->tm.preps = 0;
     return VC_OK;
 }
 

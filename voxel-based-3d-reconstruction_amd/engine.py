@@ -106,6 +106,11 @@ class CarveEngine:
             raise ValueError("masks shape %s, expected %s" % (m.shape, (self.n_cameras,) + self.image_size))
         self._check(self._L.vc_upload_masks(self._ctx, slot, _ptr(m, ctypes.c_uint8)), "vc_upload_masks")
 
+    def touch_masks(self, slot=0):
+        """Treat the slot's resident byte masks / images as new input: the next carve re-derives bit masks, block
+        grids and camera order from them on the device (no transfer)."""
+        self._check(self._L.vc_touch_masks(self._ctx, slot), "vc_touch_masks")
+
     def set_mask_postfilter(self, open2x2=None, close2x2=None):
         """Per-camera 2x2 MORPH_OPEN / MORPH_CLOSE applied on the device to every following
         upload_masks (tail of the reference's extract_foreground_mask, background_subtraction.py:195-206)."""
