@@ -69,9 +69,11 @@ typedef struct {
     float exchange_ms;  /* vc_allgather, compact form: pack + RCCL part of gather_ms         */
     float gather_ms_sum; /* summed since vc_timing_reset                                */
     uint32_t gathers;   /* vc_allgather calls since vc_timing_reset                      */
-    float prep_ms;      /* per-frame preparation queued in front of the last carve (bit-pack, boxes, grids, camera order) */
+    float prep_ms;      /* per-frame preparation queued in front of the last carve (bit-pack, boxes, grids, camera order);
+                           measured only with option timing_detail = 1 (one more event on the carve stream) */
     float prep_ms_sum;  /* summed since vc_timing_reset                                  */
     uint32_t preps;     /* carve steps that had to prepare their frame set since vc_timing_reset */
+    uint32_t preps_timed; /* ... of which prep_ms_sum holds the time                     */
 } vc_timing_t;
 
 /* ---- lifetime ------------------------------------------------------------------ */
@@ -175,6 +177,8 @@ int vc_fetch_occupancy(vc_ctx *ctx, uint8_t *bits);
  *                   refine_b (8), refine_blocks_per_cu (8), fused_blocks_per_cu (8)
  *   streams         overlap (1)  scan + record expansion of a step on a second stream, beside the next step's carve
  *                                  (single stream while a communicator is attached)
+ *   timing          timing_detail (0)  1: vc_timing's prep_ms is measured (an extra event per step on the carve stream;
+ *                                  an event between two kernels costs the stream ~10 us, so it is off by default)
  *   multi-GPU       gather_compact (1)  exchange occupancy words instead of records;
  *                   gather_sync (1)  0: vc_allgather returns once its work is queued
  * Unknown names or out-of-range values return VC_ERR_ARG. */

@@ -430,7 +430,9 @@ def test_stream_of_fresh_mask_sets_through_begin_end(eng, cams, masks, frames):
     eng.carve(slot=2, mode="lut")
     a = eng.fetch_records()
     eng.touch_masks(slot=2)
+    eng.set_option("timing_detail", 1)
     eng.carve(slot=2, mode="lut")
+    eng.set_option("timing_detail", 0)
     assert eng.timing()["prep_ms"] > 0
     assert np.array_equal(a, eng.fetch_records())
 

@@ -47,12 +47,32 @@ struct GridCam {
 // VGPRs), the block size and buffer length the preparation chose, and the camera visiting order.
 constexpr uint32_t kHdrShift = 3 * kMaxCameras;        // log2 of the block edge in pixels
 constexpr uint32_t kHdrWords = kHdrShift + 1;          // u32 words of header + grids (what the hierarchical kernels stage in LDS)
-constexpr uint32_t kHdrGridWgs = kHdrShift + 2;        // workgroups of k_prep_grid with blocks to classify (its ticket total)
-constexpr uint32_t kHdrOrder = kHdrShift + 4;          // kMaxCameras camera numbers, most selective first
-constexpr uint32_t kGridHeader = kHdrOrder + kMaxCameras;   // 68 words = 17 x 16 bytes
+constexpr uint32_t kHdrCount = kHdrShift + 4;          // kMaxCameras pass counts of a voxel sample: the camera visiting order
+constexpr uint32_t kHdrBox = kHdrCount + kMaxCameras;  // [2][kMaxCameras][4] foreground pixel boxes, double-buffered by frame parity
+constexpr uint32_t kGridHeader = kHdrBox + 2 * kMaxCameras * 4;   // 196 words = 49 x 16 bytes
 __device__ __forceinline__ uint32_t hdr_u32(const uint32_t *hdr, uint32_t i)          // wave-uniform i
 {
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr[i]);
+}
+// Camera visiting order (most selective first) from the pass counts k_prep_grid left in the header: position of
+// camera t = number of cameras with a smaller count (ties: lower camera number first).  Every workgroup works it
+// out for itself (C <= 16) into s_order; ends with a barrier.
+__device__ __forceinline__ void stage_order(const uint32_t *hdr, uint32_t C, uint32_t *s_order)
+{
+    if (threadIdx.x < C) {
+        const uint32_t mine = hdr[kHdrCount + threadIdx.x];
+        uint32_t rank = 0;
+        for (uint32_t c = 0; c < C; ++c) {
+            const uint32_t o = hdr[kHdrCount + c];
+            rank += (o < mine || (o == mine && c < threadIdx.x)) ? 1u : 0u;
+        }
+        s_order[rank] = threadIdx.x;
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ uint32_t ord(const uint32_t *s_order, uint32_t q)         // wave-uniform q
+{
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)s_order[q]);
 }
 __device__ __forceinline__ GridCam load_gridcam(const uint32_t *grids, uint32_t c)
 {
@@ -219,7 +239,14 @@ template <int KV>
 __global__ __launch_bounds__(kFirstBlock) void k_lut_first(const CarveParams p)
 {
     extern __shared__ uint32_t s_mask[];                         // first camera's mask bits
-    const uint32_t c0 = hdr_u32(p.blockgrid, kHdrOrder);
+    uint32_t c0 = 0;                                              // the most selective camera (lowest pass count)
+    {
+        uint32_t best = hdr_u32(p.blockgrid, kHdrCount);
+        for (uint32_t c = 1; c < p.C; ++c) {
+            const uint32_t v = hdr_u32(p.blockgrid, kHdrCount + c);
+            if (v < best) { best = v; c0 = c; }
+        }
+    }
     {
         const uint32_t *__restrict__ mb = p.maskbits + (size_t)c0 * p.mwords;
         for (uint32_t i = threadIdx.x; i < p.mwords; i += kFirstBlock) s_mask[i] = mb[i];
@@ -372,7 +399,8 @@ __device__ __forceinline__ void lut_refine_body(const CarveParams &p, uint32_t v
         for (uint32_t i = threadIdx.x; i < (gwords + 3) / 4; i += kBlock) dst[i] = src[i];
         __syncthreads();
     }
-    const uint32_t *hdr = HIER ? s_grid : p.blockgrid;            // camera order (and block size) of this frame set
+    __shared__ uint32_t s_order[kMaxCameras];
+    stage_order(HIER ? s_grid : p.blockgrid, p.C, s_order);       // camera order (and block size) of this frame set
     const uint32_t gshift = HIER ? hdr_u32(s_grid, kHdrShift) : 0u;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane((vblock * kBlock + threadIdx.x) >> 6);
@@ -394,11 +422,11 @@ __device__ __forceinline__ void lut_refine_body(const CarveParams &p, uint32_t v
                 uint64_t bb[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    bb[k] = (q0 + k < p.C) ? (TILE ? p.tbox : p.bbox)[(size_t)hdr_u32(hdr, kHdrOrder + q0 + k) * nwords + gw + lane] : 0ull;
+                    bb[k] = (q0 + k < p.C) ? (TILE ? p.tbox : p.bbox)[(size_t)ord(s_order, q0 + k) * nwords + gw + lane] : 0ull;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (q0 + k < p.C && cand) {
-                        const uint32_t r = box_test(s_grid, load_gridcam(s_grid, hdr_u32(hdr, kHdrOrder + q0 + k)), bb[k], gshift);
+                        const uint32_t r = box_test(s_grid, load_gridcam(s_grid, ord(s_order, q0 + k)), bb[k], gshift);
                         cand = r != 0;
                         if (r == 1) need |= 1u << (q0 + k);
                     }
@@ -438,7 +466,7 @@ __device__ __forceinline__ void lut_refine_body(const CarveParams &p, uint32_t v
                 // PAIR: two cameras' entries per dependent round trip (their loads and gathers overlap)
                 if (((ndany >> q) & (PAIR ? 3u : 1u)) == 0) continue;   // decided by the boxes for the whole batch
                 const bool two = PAIR && q + 1 < p.C;
-                const uint32_t c = hdr_u32(hdr, kHdrOrder + q), c2 = hdr_u32(hdr, kHdrOrder + (two ? q + 1 : q));
+                const uint32_t c = ord(s_order, q), c2 = ord(s_order, two ? q + 1 : q);
                 const int32_t *__restrict__ L = (TILE ? p.lut_tile : p.lut) + (size_t)c * p.n_pad + gw * 64 + lane;
                 const int32_t *__restrict__ L2 = (TILE ? p.lut_tile : p.lut) + (size_t)c2 * p.n_pad + gw * 64 + lane;
                 const uint32_t *__restrict__ mb = p.maskbits + (size_t)c * p.mwords;
@@ -504,6 +532,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 template <int KSUB, bool NY64>
 __global__ __launch_bounds__(kBlock) void k_carve_fused(const CarveParams p)
 {
+    __shared__ uint32_t s_order[kMaxCameras];
+    stage_order(p.blockgrid, p.C, s_order);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
     const uint32_t nwaves = gridDim.x * (kBlock / 64);
@@ -547,7 +577,7 @@ __global__ __launch_bounds__(kBlock) void k_carve_fused(const CarveParams p)
             }
         }
         for (uint32_t q = 0; q < p.C; ++q) {
-            const uint32_t c = hdr_u32(p.blockgrid, kHdrOrder + q);
+            const uint32_t c = ord(s_order, q);
             const uint32_t *__restrict__ mb = p.maskbits + (size_t)c * p.mwords;
 #pragma unroll
             for (int k = 0; k < KSUB; ++k) {
@@ -718,6 +748,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         for (uint32_t i = threadIdx.x; i < (gwords + 3) / 4; i += kBlock) dst[i] = src[i];
         __syncthreads();
     }
+    __shared__ uint32_t s_order[kMaxCameras];
+    stage_order(s_grid, p.C, s_order);
     const uint32_t gshift = hdr_u32(s_grid, kHdrShift);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
@@ -746,11 +778,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                 uint64_t bb[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    bb[k] = (q0 + k < p.C) ? (TILE ? p.tbox : p.bbox)[(size_t)hdr_u32(s_grid, kHdrOrder + q0 + k) * nwords + gw + lane] : 0ull;
+                    bb[k] = (q0 + k < p.C) ? (TILE ? p.tbox : p.bbox)[(size_t)ord(s_order, q0 + k) * nwords + gw + lane] : 0ull;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (q0 + k < p.C && cand) {
-                        const uint32_t r = box_test(s_grid, load_gridcam(s_grid, hdr_u32(s_grid, kHdrOrder + q0 + k)), bb[k], gshift);
+                        const uint32_t r = box_test(s_grid, load_gridcam(s_grid, ord(s_order, q0 + k)), bb[k], gshift);
                         cand = r != 0;
                         if (r == 1) need |= 1u << (q0 + k);
                     }
@@ -758,7 +790,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             }
         }
         for (uint32_t q = 0; BOX != 2 && q < p.C && __ballot(cand) != 0; ++q) {
-            const uint32_t c = hdr_u32(s_grid, kHdrOrder + q);
+            const uint32_t c = ord(s_order, q);
             if (cand) {
                 const uint64_t bb = BOX == 1 ? segment_box_f32(p.cam[c], xa, xb, ya, yb, Z, p.H, p.W)
                                              : segment_box(p.cam[c], xa, xb, ya, yb, Z, p.H, p.W);
@@ -786,7 +818,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             bool alive = true;
             for (uint32_t q = 0; q < p.C; ++q) {
                 if (!((nd >> q) & 1u)) continue;                  // decided for the whole word by its box
-                const uint32_t c = hdr_u32(s_grid, kHdrOrder + q);
+                const uint32_t c = ord(s_order, q);
                 if (alive) {
                     double u, v;
                     project_point(p.cam[c], VX, VY, VZ, u, v);
@@ -932,69 +964,45 @@ __global__ __launch_bounds__(kBlock) void k_project(const CamDev cam, const doub
 // ---------------------------------------------------------------- per-frame preparation
 // What a new frame set needs before the carve kernels can run on it, in two launches and without a
 // host round trip (the byte masks of update_visible_voxels_and_extract_colors' fg_masks argument,
-// voxel_reconstruction.py:89, are already on the device):
+// voxel_reconstruction.py:89, are already on the device).  All of it lands in the frame set's header.
 //
 //  k_prep_pack  byte masks -> bit masks (foreground where byte > 0, voxel_reconstruction.py:112) for all cameras,
 //               BGR images -> one BGRX dword per pixel (a colour sample is then a single aligned load), and each
-//               camera's foreground pixel bounding box (workgroup reduction, then atomics only where they still
-//               move the box).  The LAST workgroup to finish (ticket counter) turns the boxes into the plan of
-//               the cropped block grids -- finest power-of-two block whose grids of all cameras fit the LDS
-//               budget -- and writes it into the frame set's header.
-//  k_prep_grid  the two bits per block ("some pixel is foreground", "every pixel is foreground") of every camera's
-//               cropped grid, written as whole words from ballots (no zero-fill, no atomics), and beside them the
-//               pass counts of each camera on a sample of the slab's voxels; the last workgroup sorts the cameras
-//               by them (most selective first) into the header.  Changes the work done, never the result (the
-//               all-views test is a conjunction).
-//
-// The scratch is self-cleaning: whoever consumes it leaves it as the next launch expects it (boxes empty, counts and
-// tickets zero -- atomicInc wraps the ticket), so no memset sits between the launches.
-constexpr uint32_t kEstPerThread = 4;
-struct PrepScratch {
-    uint32_t bbox[kMaxCameras][4];     // u_min, u_max, v_min, v_max (u_min > u_max: no foreground)
-    uint32_t est[kMaxCameras];
-    uint32_t ticket[2];
-};
-
+//               camera's foreground pixel bounding box: workgroup reduction, then atomics only where they still move
+//               the box.  The boxes are double-buffered by the slot's frame parity: this launch fills one set and
+//               empties the other for the next frame, so no memset (and no fence) sits anywhere.
+//  k_prep_grid  every workgroup derives the PLAN of the cropped block grids from the boxes for itself (finest
+//               power-of-two block whose grids of all cameras fit the LDS budget; a few dozen scalar operations), then
+//               classifies its 256 blocks: two bits per block, "some pixel is foreground" and "every pixel is
+//               foreground", written as whole words from ballots (no zero-fill, no atomics).  Extra workgroups count,
+//               per camera, how many voxels of a sample of the slab it passes: the carve kernels visit the most
+//               selective camera first (stage_order).  That changes the work done, never the result (the all-views
+//               test is a conjunction).
 struct PrepParams {
     const uint8_t *src[kMaxCameras];   // byte mask of each camera (as uploaded, or post-filtered)
     const uint8_t *fsrc[kMaxCameras];  // BGR images to expand (nframes of them) ...
     uint32_t *fdst[kMaxCameras];       // ... into BGRX
     uint32_t *bits;                    // [C][mwords]
     uint32_t *grid;                    // the frame set's header + grids
-    PrepScratch *scratch;
     uint32_t C, H, W, HW, mwords, nframes;
-    uint32_t min_shift, budget_words;  // finest block, LDS budget of header + grids in u32 words
+    uint32_t parity;                   // which of the header's two box sets this frame fills
 };
-
-__device__ __forceinline__ uint32_t ld_agent(const uint32_t *p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// true in exactly one workgroup of the launch: the one that finishes last (all others' global writes are visible to it)
-__device__ __forceinline__ bool last_workgroup(uint32_t *ticket, uint32_t total, uint32_t *s_flag)
-{
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        *s_flag = (atomicInc(ticket, total - 1u) == total - 1u) ? 1u : 0u;
-    }
-    __syncthreads();
-    const bool last = *s_flag != 0;
-    if (last) __threadfence();
-    return last;
-}
 
 __global__ __launch_bounds__(kBlock) void k_prep_pack(const PrepParams p)
 {
     __shared__ uint32_t s_red[kBlock / 64][4];
-    __shared__ uint32_t s_flag;
     // workgroups [0, C * pw): camera y packs 256 mask words each; then fw per image: 1024 pixels each
     const uint32_t pw = (p.mwords + kBlock - 1) / kBlock, fw = (p.HW + 4 * kBlock - 1) / (4 * kBlock);
     const bool packing = blockIdx.x < p.C * pw;
     const uint32_t y = packing ? blockIdx.x / pw : p.C + (blockIdx.x - p.C * pw) / fw;
     const uint32_t t = (packing ? blockIdx.x - y * pw : (blockIdx.x - p.C * pw) - (y - p.C) * fw) * kBlock + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (blockIdx.x == 0 && threadIdx.x < kMaxCameras) {
+        // the sample counts of this frame start at zero (k_prep_grid adds to them); the other parity's boxes are emptied
+        p.grid[kHdrCount + threadIdx.x] = 0;
+        uint32_t *ob = p.grid + kHdrBox + ((p.parity ^ 1u) * kMaxCameras + threadIdx.x) * 4;
+        ob[0] = 0xffffffffu; ob[1] = 0; ob[2] = 0xffffffffu; ob[3] = 0;
+    }
     if (packing) {
         uint32_t u0 = 0xffffffffu, u1 = 0, v0 = 0xffffffffu, v1 = 0;
         if (t < p.mwords) {
@@ -1040,11 +1048,11 @@ __global__ __launch_bounds__(kBlock) void k_prep_pack(const PrepParams p)
                 v0 = s_red[k][2] < v0 ? s_red[k][2] : v0; v1 = s_red[k][3] > v1 ? s_red[k][3] : v1;
             }
             if (u0 != 0xffffffffu) {                              // boxes only ever grow: skip what would not move them
-                uint32_t *bb = p.scratch->bbox[y];
-                if (u0 < ld_agent(bb + 0)) atomicMin(bb + 0, u0);
-                if (u1 > ld_agent(bb + 1)) atomicMax(bb + 1, u1);
-                if (v0 < ld_agent(bb + 2)) atomicMin(bb + 2, v0);
-                if (v1 > ld_agent(bb + 3)) atomicMax(bb + 3, v1);
+                uint32_t *bb = p.grid + kHdrBox + (p.parity * kMaxCameras + y) * 4;
+                if (u0 < __hip_atomic_load(bb + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(bb + 0, u0);
+                if (u1 > __hip_atomic_load(bb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(bb + 1, u1);
+                if (v0 < __hip_atomic_load(bb + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(bb + 2, v0);
+                if (v1 > __hip_atomic_load(bb + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(bb + 3, v1);
             }
         }
     } else {
@@ -1066,50 +1074,6 @@ __global__ __launch_bounds__(kBlock) void k_prep_pack(const PrepParams p)
                 dst[i] = (uint32_t)src[3 * i] | ((uint32_t)src[3 * i + 1] << 8) | ((uint32_t)src[3 * i + 2] << 16);
         }
     }
-    if (!last_workgroup(&p.scratch->ticket[0], gridDim.x, &s_flag)) return;
-    if (wave != 0) return;
-    // ---- plan of the cropped block grids (wave 0 of the last workgroup).  lane = candidate shift: words needed
-    const uint32_t shift_c = lane < 15u ? lane : 14u;
-    uint32_t total = kGridHeader;
-    for (uint32_t c = 0; c < p.C; ++c) {
-        const uint32_t b0 = ld_agent(&p.scratch->bbox[c][0]), b1 = ld_agent(&p.scratch->bbox[c][1]);
-        const uint32_t b2 = ld_agent(&p.scratch->bbox[c][2]), b3 = ld_agent(&p.scratch->bbox[c][3]);
-        if (b0 > b1) continue;
-        const uint32_t cws = ((b1 >> shift_c) >> 5) - ((b0 >> shift_c) >> 5) + 1u;
-        const uint32_t ch = (b3 >> shift_c) - (b2 >> shift_c) + 1u;
-        total += 2u * cws * ch;
-    }
-    // W <= 65535, H <= 32767: at 2^14-pixel blocks every grid is a few words, so a shift is always found
-    const uint64_t fits = __ballot(lane >= p.min_shift && lane < 15u && (total <= p.budget_words || lane == 14u));
-    const uint32_t shift = (uint32_t)__builtin_ctzll(fits);
-    // lane = camera: its descriptor at the chosen shift
-    uint32_t w_lo = 0, v_lo = 0, cws = 0, ch = 0;
-    if (lane < p.C) {
-        const uint32_t b0 = ld_agent(&p.scratch->bbox[lane][0]), b1 = ld_agent(&p.scratch->bbox[lane][1]);
-        const uint32_t b2 = ld_agent(&p.scratch->bbox[lane][2]), b3 = ld_agent(&p.scratch->bbox[lane][3]);
-        if (b0 <= b1) {
-            w_lo = (b0 >> shift) >> 5; cws = ((b1 >> shift) >> 5) - w_lo + 1u;
-            v_lo = b2 >> shift; ch = (b3 >> shift) - v_lo + 1u;
-        }
-    }
-    const uint32_t size = 2u * cws * ch;
-    const uint32_t incl = wave_inclusive_scan(size, lane);
-    if (lane < kMaxCameras) {
-        p.grid[3 * lane] = kGridHeader + incl - size;
-        p.grid[3 * lane + 1] = w_lo | (v_lo << 16);
-        p.grid[3 * lane + 2] = cws | (ch << 16);
-        uint32_t *bb = p.scratch->bbox[lane];                     // leave the scratch empty for the next frame set
-        bb[0] = 0xffffffffu; bb[1] = 0; bb[2] = 0xffffffffu; bb[3] = 0;
-    }
-    // workgroups of k_prep_grid that will have blocks to look at (the others leave without drawing a ticket)
-    uint32_t wgs = (32u * cws * ch + kBlock - 1) / kBlock;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) wgs += __shfl_xor(wgs, d);
-    if (lane == 63) {
-        p.grid[kHdrShift] = shift;
-        p.grid[kHdrWords] = kGridHeader + incl;
-        p.grid[kHdrGridWgs] = wgs;
-    }
 }
 
 // "any" and "all" of the pixels [o, o + len) of a bit mask, len >= 1
@@ -1127,83 +1091,101 @@ __device__ __forceinline__ void span_any_all(const uint32_t *__restrict__ mb, ui
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_prep_grid(const CarveParams p, uint32_t *__restrict__ grid, PrepScratch *scratch,
-                                                      uint32_t nsamples, uint32_t reorder)
+constexpr uint32_t kEstPerThread = 4;
+
+__global__ __launch_bounds__(kBlock) void k_prep_grid(const CarveParams p, uint32_t *grid, uint32_t parity, uint32_t min_shift,
+                                                      uint32_t budget_words, uint32_t nsamples)
 {
-    __shared__ uint32_t s_flag;
     const uint32_t y = blockIdx.y;
     const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     if (y < p.C) {
-        const GridCam gc = load_gridcam(grid, y);
-        const uint32_t shift = hdr_u32(grid, kHdrShift);
-        const uint32_t bw = (uint32_t)gc.cws * 32u, nb = bw * gc.ch;     // block columns kept, blocks kept
-        if (blockIdx.x * kBlock >= nb) return;                           // (workgroup-uniform; not counted in the ticket)
-        {
-            bool any = false, all = false;
-            if (t < nb) {
-                const uint32_t rv = t / bw, ru = t - rv * bw;
-                const uint32_t bv = gc.v_lo + rv, bu = (uint32_t)gc.w_lo * 32u + ru;
-                const uint32_t x0 = bu << shift, y0 = bv << shift;
-                if (x0 < p.W && y0 < p.H) {
-                    const uint32_t x1 = ((bu + 1u) << shift) < p.W ? ((bu + 1u) << shift) : p.W;
-                    const uint32_t y1 = ((bv + 1u) << shift) < p.H ? ((bv + 1u) << shift) : p.H;
-                    const uint32_t *mb = p.maskbits + (size_t)y * p.mwords;
-                    all = true;
-                    for (uint32_t yy = y0; yy < y1; ++yy) span_any_all(mb, yy * p.W + x0, x1 - x0, any, all);
-                }
-            }
-            // bw is a multiple of 32 and a wave starts at a multiple of 64: each half-wave is one grid word
-            const uint64_t bany = __ballot(any), ball = __ballot(all);
-            if ((lane & 31u) == 0 && t < nb) {
-                const uint32_t rv = t / bw, ru = t - rv * bw;
-                const uint32_t w = gc.off + rv * gc.cws + (ru >> 5);
-                grid[w] = (uint32_t)(bany >> lane);
-                grid[w + (uint32_t)gc.ch * gc.cws] = (uint32_t)(ball >> lane);
+        // ---- the plan, by every wave for itself.  lane = candidate shift: words the grids of all cameras would take
+        const uint32_t *box = grid + kHdrBox + parity * kMaxCameras * 4;
+        const uint32_t shift_c = lane < 15u ? lane : 14u;
+        uint32_t total = kGridHeader;
+        for (uint32_t c = 0; c < p.C; ++c) {
+            const uint32_t b0 = hdr_u32(box, 4 * c), b1 = hdr_u32(box, 4 * c + 1), b2 = hdr_u32(box, 4 * c + 2), b3 = hdr_u32(box, 4 * c + 3);
+            if (b0 > b1) continue;                                // no foreground in this camera
+            total += 2u * (((b1 >> shift_c) >> 5) - ((b0 >> shift_c) >> 5) + 1u) * ((b3 >> shift_c) - (b2 >> shift_c) + 1u);
+        }
+        // W <= 65535, H <= 32767: at 2^14-pixel blocks every grid is a few words, so a shift is always found
+        const uint64_t fits = __ballot(lane >= min_shift && lane < 15u && (total <= budget_words || lane == 14u));
+        const uint32_t shift = (uint32_t)__builtin_ctzll(fits);
+        // lane = camera: its descriptor at the chosen shift, offsets by a scan over the cameras
+        uint32_t w_lo = 0, v_lo = 0, cws = 0, ch = 0;
+        if (lane < p.C) {
+            const uint32_t b0 = box[4 * lane], b1 = box[4 * lane + 1], b2 = box[4 * lane + 2], b3 = box[4 * lane + 3];
+            if (b0 <= b1) {
+                w_lo = (b0 >> shift) >> 5; cws = ((b1 >> shift) >> 5) - w_lo + 1u;
+                v_lo = b2 >> shift; ch = (b3 >> shift) - v_lo + 1u;
             }
         }
-    } else {
-        // pass count of each camera on `nsamples` evenly spaced voxels of the slab, kEstPerThread per thread
-        if (blockIdx.x * kBlock * kEstPerThread >= nsamples) return;
-        double X[kEstPerThread], Y[kEstPerThread], Z[kEstPerThread];
-        uint32_t valid = 0;
+        const uint32_t size = 2u * cws * ch;
+        const uint32_t incl = wave_inclusive_scan(size, lane);
+        if (blockIdx.x == 0 && y == 0 && threadIdx.x < 64u) {    // one wave of the launch records the plan for the carve kernels
+            if (lane < kMaxCameras) {
+                grid[3 * lane] = kGridHeader + incl - size;
+                grid[3 * lane + 1] = w_lo | (v_lo << 16);
+                grid[3 * lane + 2] = cws | (ch << 16);
+            }
+            if (lane == 63) { grid[kHdrShift] = shift; grid[kHdrWords] = kGridHeader + incl; }
+        }
+        // ---- this workgroup's 256 blocks of camera y
+        const uint32_t g_off = kGridHeader + (uint32_t)__builtin_amdgcn_readlane((int)(incl - size), (int)y);
+        const uint32_t g_wlo = (uint32_t)__builtin_amdgcn_readlane((int)w_lo, (int)y), g_vlo = (uint32_t)__builtin_amdgcn_readlane((int)v_lo, (int)y);
+        const uint32_t g_cws = (uint32_t)__builtin_amdgcn_readlane((int)cws, (int)y), g_ch = (uint32_t)__builtin_amdgcn_readlane((int)ch, (int)y);
+        const uint32_t bw = g_cws * 32u, nb = bw * g_ch;          // block columns kept, blocks kept
+        if (blockIdx.x * kBlock >= nb) return;
+        bool any = false, all = false;
+        if (t < nb) {
+            const uint32_t rv = t / bw, ru = t - rv * bw;
+            const uint32_t bv = g_vlo + rv, bu = g_wlo * 32u + ru;
+            const uint32_t x0 = bu << shift, y0 = bv << shift;
+            if (x0 < p.W && y0 < p.H) {
+                const uint32_t x1 = ((bu + 1u) << shift) < p.W ? ((bu + 1u) << shift) : p.W;
+                const uint32_t y1 = ((bv + 1u) << shift) < p.H ? ((bv + 1u) << shift) : p.H;
+                const uint32_t *mb = p.maskbits + (size_t)y * p.mwords;
+                all = true;
+                for (uint32_t yy = y0; yy < y1; ++yy) span_any_all(mb, yy * p.W + x0, x1 - x0, any, all);
+            }
+        }
+        // bw is a multiple of 32 and a wave starts at a multiple of 64: each half-wave is one grid word
+        const uint64_t bany = __ballot(any), ball = __ballot(all);
+        if ((lane & 31u) == 0 && t < nb) {
+            const uint32_t rv = t / bw, ru = t - rv * bw;
+            const uint32_t w = g_off + rv * g_cws + (ru >> 5);
+            grid[w] = (uint32_t)(bany >> lane);
+            grid[w + g_ch * g_cws] = (uint32_t)(ball >> lane);
+        }
+        return;
+    }
+    // ---- pass count of each camera on `nsamples` evenly spaced voxels of the slab, kEstPerThread per thread
+    if (blockIdx.x * kBlock * kEstPerThread >= nsamples) return;
+    double X[kEstPerThread], Y[kEstPerThread], Z[kEstPerThread];
+    uint32_t valid = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kEstPerThread; ++k) {
+        const uint32_t sidx = (blockIdx.x * kEstPerThread + k) * kBlock + threadIdx.x;
+        uint32_t ix = 0, iy = 0, izl = 0;
+        if (sidx < nsamples) {
+            valid |= 1u << k;
+            decompose((uint32_t)(((uint64_t)sidx * p.n) / nsamples), p.nx, p.ny, ix, iy, izl);
+        }
+        X[k] = p.xs[ix]; Y[k] = p.ys[iy]; Z[k] = p.zs[p.z0 + izl];
+    }
+    for (uint32_t c = 0; c < p.C; ++c) {
+        uint32_t hits = 0;
 #pragma unroll
         for (uint32_t k = 0; k < kEstPerThread; ++k) {
-            const uint32_t sidx = (blockIdx.x * kEstPerThread + k) * kBlock + threadIdx.x;
-            uint32_t ix = 0, iy = 0, izl = 0;
-            if (sidx < nsamples) {
-                valid |= 1u << k;
-                decompose((uint32_t)(((uint64_t)sidx * p.n) / nsamples), p.nx, p.ny, ix, iy, izl);
-            }
-            X[k] = p.xs[ix]; Y[k] = p.ys[iy]; Z[k] = p.zs[p.z0 + izl];
+            double u, v;
+            project_point(p.cam[c], X[k], Y[k], Z[k], u, v);
+            const int32_t off = pixel_offset(u, v, p.H, p.W);
+            const bool hit = ((valid >> k) & 1u) && off >= 0 && mask_bit(p.maskbits + (size_t)c * p.mwords, off);
+            hits += (uint32_t)__popcll(__ballot(hit));
         }
-        for (uint32_t c = 0; c < p.C; ++c) {
-            uint32_t hits = 0;
-#pragma unroll
-            for (uint32_t k = 0; k < kEstPerThread; ++k) {
-                double u, v;
-                project_point(p.cam[c], X[k], Y[k], Z[k], u, v);
-                const int32_t off = pixel_offset(u, v, p.H, p.W);
-                const bool hit = ((valid >> k) & 1u) && off >= 0 && mask_bit(p.maskbits + (size_t)c * p.mwords, off);
-                hits += (uint32_t)__popcll(__ballot(hit));
-            }
-            if (lane == 0 && hits) atomicAdd(&scratch->est[c], hits);
-        }
+        if (lane == 0 && hits) atomicAdd(&grid[kHdrCount + c], hits);
     }
-    const uint32_t est_wgs = (nsamples + kBlock * kEstPerThread - 1) / (kBlock * kEstPerThread);
-    if (!last_workgroup(&scratch->ticket[1], hdr_u32(grid, kHdrGridWgs) + est_wgs, &s_flag)) return;
-    if (threadIdx.x != 0) return;
-    uint32_t order[kMaxCameras], cnt[kMaxCameras];
-    for (uint32_t c = 0; c < kMaxCameras; ++c) {
-        order[c] = c;
-        cnt[c] = (c < p.C && reorder) ? ld_agent(&scratch->est[c]) : 0u;
-        scratch->est[c] = 0;
-    }
-    for (uint32_t a = 1; a < p.C; ++a)                            // stable insertion sort, ascending pass count
-        for (uint32_t b = a; b > 0 && cnt[order[b]] < cnt[order[b - 1]]; --b) {
-            const uint32_t x = order[b]; order[b] = order[b - 1]; order[b - 1] = x;
-        }
-    for (uint32_t c = 0; c < kMaxCameras; ++c) grid[kHdrOrder + c] = order[c];
 }
 
 // ---------------------------------------------------------------- compaction

@@ -102,7 +102,13 @@ struct Slot {
     bool grids_valid = false;   // block grids and camera order too (they also depend on grid, slab and cameras)
     DevBuf<uint32_t> grid;      // header + cropped block grids of all cameras (hierarchical kernels stage it in LDS)
     uint32_t budget_words = 0;  // LDS budget the plan was made for (fixes the dynamic LDS size of the carve launch)
-    hipEvent_t e_up = nullptr, e_read = nullptr, e_emit = nullptr;   // last upload | last read of the bytes | last expansion reading bits / images
+    uint32_t parity = 0;        // which of the header's two foreground-box sets the current frame filled
+    bool counts_zero = false;   // the header's sample counts are zero (k_prep_pack just ran)
+    hipEvent_t e_up = nullptr;  // last upload into this slot (owned; upload stream)
+    // borrowed from the step that used the slot last (recording an event between two kernels costs ~10 us of stream time,
+    // so the slot rides on the events a step records anyway): a point behind the last kernel that read the uploaded
+    // bytes, and one behind the last record expansion that read the slot's bits / images on the second stream
+    hipEvent_t e_read = nullptr, e_emit = nullptr;
     bool up_pending = false, read_pending = false, emit_pending = false;
 };
 
@@ -135,7 +141,7 @@ struct StepBuf {
     DevBuf<uint64_t> records;
     uint64_t *h_total = nullptr;             // pinned
     hipEvent_t e0 = nullptr, e_first = nullptr, e1 = nullptr, e2 = nullptr, e_scan = nullptr, e_prep = nullptr;
-    bool prepped = false;                    // this step queued preparation kernels in front of its carve (e_prep .. e0)
+    bool prepped = false, prep_timed = false; // this step queued preparation kernels in front of its carve (timed: e_prep .. e0)
     bool pending = false, used = false;
     EmitParams emit;                         // kept for a re-run after a records regrow
     bool allseen = false, want_vm = false, has_first = false;
@@ -157,7 +163,6 @@ struct vc_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // scan + record expansion of step i, beside the carve of step i+1 on `stream`
     hipStream_t stream_up = nullptr; // host-to-device copies of masks and images (overlap the carve in flight)
-    DevBuf<PrepScratch> d_prep;      // self-cleaning scratch of the per-frame preparation kernels
     hipEvent_t ev_h[2] = {nullptr, nullptr};   // around the last mask upload (h2d_ms)
     bool h2d_pending = false;
     int overlap = 1;                 // (one stream when a communicator is attached: its collectives order everything)
@@ -211,6 +216,7 @@ struct vc_ctx {
     int emit_waves_per_cu = 256;     // waves of that launch per CU (a wave strides over the list when there are more busy groups)
     int fused_hier = 1;              // VC_MODE_FUSED: interval-arithmetic word rejection (needs ny % 64 == 0)
     int lut_hier = 1;                // VC_MODE_LUT: hierarchical kernel (boxes + block grid) instead of stream + refine
+    int timing_detail = 0;           // also time the per-frame preparation of each step (one more event on the carve stream)
     DevBuf<uint16_t> d_viewmask;
     DevBuf<double> d_scratch;
     uint64_t *h_total = nullptr;     // pinned scalar (all-gather count)
@@ -332,8 +338,6 @@ int slot_at(vc_ctx *ctx, uint32_t slot, Slot **out)
     if (s.have_frame.size() != ctx->C) { s.have_frame.assign(ctx->C, 0); s.frame_dirty.assign(ctx->C, 0); }
     if (!s.e_up) {
         VC_HIP(ctx, hipEventCreateWithFlags(&s.e_up, hipEventDisableTiming));
-        VC_HIP(ctx, hipEventCreateWithFlags(&s.e_read, hipEventDisableTiming));
-        VC_HIP(ctx, hipEventCreateWithFlags(&s.e_emit, hipEventDisableTiming));
     }
     *out = &s;
     return VC_OK;
@@ -360,20 +364,22 @@ int ensure_prepared(vc_ctx *ctx, Slot &s, bool want_grids, const CarveParams *cp
 {
     const uint32_t C = ctx->C;
     const size_t HW = (size_t)ctx->H * ctx->W;
-    if (!ctx->d_prep.ptr) {
-        VC_TRY(ensure(ctx, ctx->d_prep, 1));
-        PrepScratch init;
-        memset(&init, 0, sizeof init);
-        for (uint32_t c = 0; c < kMaxCameras; ++c) { init.bbox[c][0] = 0xffffffffu; init.bbox[c][2] = 0xffffffffu; }
-        VC_HIP(ctx, hipMemcpy(ctx->d_prep.ptr, &init, sizeof init, hipMemcpyHostToDevice));
-    }
     if (!s.bits_valid) {
         if (s.up_pending) VC_HIP(ctx, hipStreamWaitEvent(ctx->stream, s.e_up, 0));
         if (s.emit_pending) { VC_HIP(ctx, hipStreamWaitEvent(ctx->stream, s.e_emit, 0)); s.emit_pending = false; }
         VC_TRY(ensure(ctx, s.bits, (size_t)ctx->mwords * C));
-        const uint32_t budget = (uint32_t)ctx->grid_lds_kb * 256u;            // u32 words
-        VC_TRY(ensure(ctx, s.grid, (size_t)(budget > 256u ? budget : 256u) + 8));   // + padding: kernels copy it 16 bytes at a time
+        uint32_t budget = (uint32_t)ctx->grid_lds_kb * 256u;                  // u32 words of header + grids
+        if (budget < kGridHeader + 128u) budget = kGridHeader + 128u;         // room for every camera's grid at the coarsest block
+        if (budget + 8 > s.grid.cap || !s.grid.ptr) {
+            VC_TRY(ensure(ctx, s.grid, (size_t)budget + 8));                   // + padding: kernels copy it 16 bytes at a time
+            std::vector<uint32_t> init(s.grid.cap, 0u);                        // both box sets start empty
+            for (uint32_t k = 0; k < 2 * kMaxCameras; ++k) { init[kHdrBox + 4 * k] = 0xffffffffu; init[kHdrBox + 4 * k + 2] = 0xffffffffu; }
+            VC_HIP(ctx, hipMemcpyAsync(s.grid.ptr, init.data(), init.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+            VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            s.parity = 0;
+        }
         s.budget_words = budget;
+        s.parity ^= 1u;
         PrepParams pp;
         memset(&pp, 0, sizeof pp);
         for (uint32_t c = 0; c < C; ++c) {
@@ -404,27 +410,29 @@ int ensure_prepared(vc_ctx *ctx, Slot &s, bool want_grids, const CarveParams *cp
             pp.nframes++;
             s.frame_dirty[c] = 0;
         }
-        pp.bits = s.bits.ptr; pp.grid = s.grid.ptr; pp.scratch = ctx->d_prep.ptr;
+        pp.bits = s.bits.ptr; pp.grid = s.grid.ptr;
         pp.C = C; pp.H = ctx->H; pp.W = ctx->W; pp.HW = (uint32_t)HW; pp.mwords = ctx->mwords;
-        pp.min_shift = (uint32_t)ctx->grid_min_shift; pp.budget_words = budget;
+        pp.parity = s.parity;
         const uint32_t pw = (ctx->mwords + kBlock - 1) / kBlock, fw = (uint32_t)((HW + 4 * kBlock - 1) / (4 * kBlock));
         hipLaunchKernelGGL(k_prep_pack, dim3(C * pw + pp.nframes * fw), dim3(kBlock), 0, ctx->stream, pp);
         VC_HIP(ctx, hipGetLastError());
-        VC_HIP(ctx, hipEventRecord(s.e_read, ctx->stream));
-        s.read_pending = true;
+        s.read_pending = false;          // the caller points e_read at an event it records behind these kernels
         s.bits_valid = true;
         s.grids_valid = false;
+        s.counts_zero = true;
     }
     if (want_grids && !s.grids_valid) {
         CarveParams p = *cp;
         p.maskbits = s.bits.ptr;
         const uint64_t n = p.n;
         const uint32_t ns = (uint32_t)(n < kEstimateSamples ? n : kEstimateSamples);
-        const uint32_t est_wgs = (ns + kBlock * kEstPerThread - 1) / (kBlock * kEstPerThread);
+        const uint32_t est_wgs = ctx->reorder ? (ns + kBlock * kEstPerThread - 1) / (kBlock * kEstPerThread) : 0u;   // no counts: cameras in index order
+        if (!s.counts_zero) VC_HIP(ctx, hipMemsetAsync(s.grid.ptr + kHdrCount, 0, sizeof(uint32_t) * kMaxCameras, ctx->stream));
+        s.counts_zero = false;
         // a camera's grids hold at most 16 blocks per budgeted word
-        const uint32_t grid_wgs = (16u * (s.budget_words > 256u ? s.budget_words : 256u) + kBlock - 1) / kBlock;
-        hipLaunchKernelGGL(k_prep_grid, dim3(grid_wgs > est_wgs ? grid_wgs : est_wgs, C + 1), dim3(kBlock), 0, ctx->stream, p,
-                           s.grid.ptr, ctx->d_prep.ptr, ns, (uint32_t)(ctx->reorder ? 1 : 0));
+        const uint32_t grid_wgs = (16u * s.budget_words + kBlock - 1) / kBlock;
+        hipLaunchKernelGGL(k_prep_grid, dim3(grid_wgs > est_wgs ? grid_wgs : est_wgs, C + (est_wgs ? 1 : 0)), dim3(kBlock), 0, ctx->stream, p,
+                           s.grid.ptr, s.parity, (uint32_t)ctx->grid_min_shift, s.budget_words, ns);
         VC_HIP(ctx, hipGetLastError());
         s.grids_valid = true;
     }
@@ -638,11 +646,6 @@ int enqueue_expand(vc_ctx *ctx, hipStream_t st, const uint64_t *d_entries, uint6
     else if (cur.allseen) hipLaunchKernelGGL((k_emit_lanes<false, true, 4, true>), grid, block, 0, st, e);
     else hipLaunchKernelGGL((k_emit_lanes<false, false, 4, true>), grid, block, 0, st, e);
     VC_HIP(ctx, hipGetLastError());
-    if (cur.color_cam >= 0 && st != ctx->stream) {               // reads the slot's bits / images beside the carve stream
-        Slot &s = ctx->slots[cur.slot];
-        VC_HIP(ctx, hipEventRecord(s.e_emit, st));
-        s.emit_pending = true;
-    }
     return VC_OK;
 }
 
@@ -718,10 +721,7 @@ int vc_destroy(vc_ctx *ctx)
     for (Slot &s : ctx->slots) {
         release_slot(s);
         if (s.e_up) (void)hipEventDestroy(s.e_up);
-        if (s.e_read) (void)hipEventDestroy(s.e_read);
-        if (s.e_emit) (void)hipEventDestroy(s.e_emit);
     }
-    release(ctx->d_prep);
     for (int k = 0; k < 2; ++k) if (ctx->ev_h[k]) (void)hipEventDestroy(ctx->ev_h[k]);
     release(ctx->d_axes); release(ctx->d_morph); release(ctx->d_lut); release(ctx->d_bbox); release(ctx->d_lut_tile); release(ctx->d_tbox);
     for (StepBuf &b : ctx->sb) {
@@ -915,7 +915,7 @@ int vc_fetch_mask(vc_ctx *ctx, uint32_t slot, uint32_t cam, uint8_t *out)
     if (cam >= ctx->C) return fail(ctx, VC_ERR_ARG, "camera %u not in [0,%u)", cam, ctx->C);
     VC_HIP(ctx, hipSetDevice(ctx->device));
     VC_TRY(ensure_prepared(ctx, ctx->slots[slot], false, nullptr));
-    VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    VC_HIP(ctx, hipStreamSynchronize(ctx->stream));       // (nothing reads the uploaded bytes any more)
     std::vector<uint32_t> bits(ctx->mwords);
     VC_HIP(ctx, hipMemcpy(bits.data(), ctx->slots[slot].bits.ptr + (size_t)cam * ctx->mwords, sizeof(uint32_t) * ctx->mwords,
                           hipMemcpyDeviceToHost));
@@ -1075,11 +1075,13 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     if (mode == VC_MODE_LUT && !ctx->lut_hier && (size_t)ctx->mwords * sizeof(uint32_t) > kMaxFirstLds) fast = false;
     // per-frame preparation, on the device, in front of the carve (nothing to do when the slot has been used before)
     sb.prepped = !s.bits_valid || (fast && !s.grids_valid);
-    if (sb.prepped) VC_HIP(ctx, hipEventRecord(sb.e_prep, ctx->stream));
+    sb.prep_timed = sb.prepped && ctx->timing_detail;
+    if (sb.prep_timed) VC_HIP(ctx, hipEventRecord(sb.e_prep, ctx->stream));
+    const bool read_bytes = !s.bits_valid;
     VC_TRY(ensure_prepared(ctx, s, fast, &p));
     p.maskbits = s.bits.ptr;
     p.blockgrid = s.grid.ptr;
-    const size_t grid_lds = ((size_t)(s.budget_words > 256u ? s.budget_words : 256u) + 8) * sizeof(uint32_t);
+    const size_t grid_lds = ((size_t)s.budget_words + 8) * sizeof(uint32_t);
 
     VC_HIP(ctx, hipEventRecord(sb.e0, ctx->stream));
     const dim3 block(kBlock);
@@ -1106,8 +1108,6 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
             else if (ctx->refine_pair) hipLaunchKernelGGL((k_lut_refine<8, true, true>), rgrid, block, lds, ctx->stream, p);
             else if (ctx->refine_b == 8) hipLaunchKernelGGL((k_lut_refine<8, true, false>), rgrid, block, lds, ctx->stream, p);
             else hipLaunchKernelGGL((k_lut_refine<16, true, false>), rgrid, block, lds, ctx->stream, p);
-            VC_HIP(ctx, hipEventRecord(sb.e_first, ctx->stream));
-            sb.has_first = true;
         } else if (mode == VC_MODE_LUT) {
             const size_t lds = (size_t)ctx->mwords * sizeof(uint32_t);
             const int kv = ctx->first_kv;
@@ -1173,6 +1173,7 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     }
     VC_HIP(ctx, hipGetLastError());
     VC_HIP(ctx, hipEventRecord(sb.e1, ctx->stream));
+    if (read_bytes) { s.e_read = sb.e1; s.read_pending = true; }   // an upload into this slot waits for the kernels that read its bytes
 
     // ---- compaction: group counts -> two-level scan -> record expansion
     // the carve kernels are VALU-issue bound, the expansion is memory bound: on its own stream the expansion of this
@@ -1239,7 +1240,6 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     }
     if (!sb.no_records) {
         VC_TRY(launch_emit(ctx, sb, s3));
-        if (s3 != ctx->stream) { VC_HIP(ctx, hipEventRecord(s.e_emit, s3)); s.emit_pending = true; }   // reads the slot's bits / images
     }
     if (auto_exchange) {
         VC_TRY(enqueue_pack(ctx, sb));
@@ -1247,6 +1247,7 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
         sb.counts_exchanged = true;
     }
     VC_HIP(ctx, hipEventRecord(sb.e2, sb.no_records ? s2 : s3));
+    if (!sb.no_records && s3 != ctx->stream) { s.e_emit = sb.e2; s.emit_pending = true; }   // the expansion reads the slot's bits / images
     sb.pending = true;
     sb.used = true;
     ctx->head ^= 1;
@@ -1282,15 +1283,17 @@ int vc_carve_end(vc_ctx *ctx, uint64_t *n_out)
         ctx->tm.carve_ms = ms;
         ctx->tm.first_ms = 0;
         if (sb.has_first) VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.first_ms, sb.e0, sb.e_first));
+        else ctx->tm.first_ms = ms;                       // one kernel does the whole carve
         ctx->tm.first_ms_sum += ctx->tm.first_ms;
         ctx->tm.carve_ms_sum += ms;
         ctx->tm.carve_launches += 1;
         VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.compact_ms, sb.e1, sb.e2));
         ctx->tm.prep_ms = 0;
-        if (sb.prepped) {
+        if (sb.prepped) ctx->tm.preps += 1;
+        if (sb.prep_timed) {
             VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.prep_ms, sb.e_prep, sb.e0));
             ctx->tm.prep_ms_sum += ctx->tm.prep_ms;
-            ctx->tm.preps += 1;
+            ctx->tm.preps_timed += 1;
         }
     } else {
         if (sb.counts_exchanged) VC_HIP(ctx, hipEventSynchronize(sb.e2));
@@ -1404,6 +1407,7 @@ int vc_set_option(vc_ctx *ctx, const char *name, int value)
     else if (k == "fused_hier") ctx->fused_hier = value != 0;
     else if (k == "emit_lanes") ctx->emit_lanes = value != 0;
     else if (k == "overlap") ctx->overlap = value != 0;
+    else if (k == "timing_detail") ctx->timing_detail = value != 0;
     else if (k == "emit_busy" && value >= 0 && value <= 2) ctx->emit_busy = value;          // 0 never, 1 large grids, 2 always
     else if (k == "emit_waves_per_cu" && value >= 4 && value <= 1024) ctx->emit_waves_per_cu = value;
     else if (k == "lut_tile") ctx->lut_tile = value != 0;
@@ -1448,6 +1452,7 @@ int vc_timing_reset(vc_ctx *ctx)
     ctx->tm.gathers = 0;
     ctx->tm.prep_ms_sum = 0;
     ctx->tm.preps = 0;
+    ctx->tm.preps_timed = 0;
     return VC_OK;
 }
 
@@ -1582,6 +1587,11 @@ static int allgather_compact(vc_ctx *ctx, uint64_t *counts_out, uint64_t *total_
     if (xs != ctx->stream) VC_HIP(ctx, hipStreamWaitEvent(xs, ctx->ev[2], 0));
     if (S) VC_TRY(enqueue_expand(ctx, xs, ctx->d_ent_all.ptr, M, S));
     VC_HIP(ctx, hipEventRecord(ctx->ev[1], xs));
+    if (S && cur.color_cam >= 0 && xs != ctx->stream) {          // the expansion reads the slot's bits / images beside the carve stream
+        Slot &sl = ctx->slots[cur.slot];
+        sl.e_emit = ctx->ev[1];
+        sl.emit_pending = true;
+    }
     ctx->gather_pending = true;
     ctx->gather_expect = S;
     if (counts_out) for (int r = 0; r < G; ++r) counts_out[r] = cur.h_counts[2 * r + 1];
