@@ -164,6 +164,7 @@ int vc_fetch_occupancy(vc_ctx *ctx, uint8_t *bits);
  * (tests/test_gpu_parity.py runs every family against the oracle).  Defaults are the measured best on MI355X.
  *   kernel choice   lut_hier (1)  hierarchical lookup-table kernel, 0 = stream the table (k_lut_first + refine)
  *                   lut_tile, fused_tile (1)  words of 4 x-rows x 16 y where nx % 4 == 0 and ny % 64 == 0
+ *                   cull (1)  those kernels first decide whole 16 x 16 x 16-voxel bricks from the bricks' pixel boxes (k_cull)
  *                   fused_hier (1), fused_boxes (1), fused_f32box (1)  table-free kernel: word rejection; boxes read /
  *                                  bounded on the fly in float32 / float64 intervals
  *                   fused_color_table (0)  table-free carve, survivors coloured from the colour camera's table (4 B per

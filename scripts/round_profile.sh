@@ -1,28 +1,35 @@
 # Round profile: bench line, rocprofv3 kernel stats, PMC traffic passes.  Outputs under gpurun_out/<tag>/.
 TAG=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
-cd $GRAFT_REPO_ROOT && python bench.py "$@" > $OUT/bench.json 2> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
+if [ -z "$PMC_ONLY" ]; then
+cd $GRAFT_REPO_ROOT && python bench.py "$@" > $OUT/bench.json 2> $OUT/bench.err
+cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $GRAFT_REPO_ROOT/bench.py "$@" --no-cpu-baseline > $OUT/stats.log 2>&1
-for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"; do
-  tag=$(echo $set | tr ' ' '_')
+fi
+SETS=("FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE" \
+      "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU" \
+      "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA")
+for set in "${SETS[@]}"; do
+  tag=$(echo $set | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/pmc_$tag -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_$tag.log 2>&1 || echo "pass $tag failed"
 done
 cd $GRAFT_REPO_ROOT
 python3 - <<PY
 import csv, glob, collections, json
 out = "$OUT"
-print(open(out + "/bench.json").read()[:3000])
+import os
+if os.path.exists(out + "/bench.json"): print(open(out + "/bench.json").read()[:3000])
 for f in glob.glob(out + "/stats/*/*kernel_stats.csv"):
     print(open(f).read())
 agg = collections.defaultdict(lambda: [0, 0.0])
 for f in sorted(glob.glob(out + "/pmc_*/*/*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        k = (r["Kernel_Name"].split("(")[0][-44:], r["Counter_Name"])
+        k = (r["Kernel_Name"].split("(")[0][-48:], r["Counter_Name"])
         agg[k][0] += 1; agg[k][1] += float(r["Counter_Value"])
 rows = {}
 for (kn, cn), (n, v) in sorted(agg.items()):
-    if any(t in kn for t in ("k_lut", "k_carve", "k_emit", "k_scan", "k_build")):
+    if any(t in kn for t in ("k_lut", "k_carve", "k_emit", "k_scan", "k_build", "k_prep", "k_finish", "k_cull")):
         print("%-42s %-18s calls=%3d avg=%.6g" % (kn, cn, n, v / n))
         rows.setdefault(kn, {})[cn] = v / n
 json.dump(rows, open(out + "/pmc_summary.json", "w"), indent=1)

@@ -149,7 +149,7 @@ def test_random_scenes_ragged_shapes(eng, seed):
                     assert np.array_equal(eng.fetch_viewmask(), want["viewmask"])
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", range(8))
 def test_every_kernel_family_agrees_with_oracle(eng, seed):
     """The same scene through each carve implementation: hierarchical LUT on tile words (default where nx % 4 == 0 and
     ny % 64 == 0; grid 2 is the case whose waves do not coincide with y-major groups) and on y-line words, streaming LUT
@@ -157,7 +157,8 @@ def test_every_kernel_family_agrees_with_oracle(eng, seed):
     hierarchical kernels leave the words of dead groups unwritten and vc_fetch_occupancy has to fill them in."""
     from oracle import carve_c
     cams3, masks3, frames3 = fx.random_scene(100 + seed, C=4, H=60 + 7 * seed, W=80, fg=0.55)
-    grid = [(16, 128, 24), (40, 64, 9), (8, 192, 33), (5, 70, 19)][seed]        # last: ny % 64 != 0
+    # 4th: ny % 64 != 0; the last four are strip shapes (ny in {256, 512, 1024}), with partial bricks in x and z
+    grid = [(16, 128, 24), (40, 64, 9), (8, 192, 33), (5, 70, 19), (16, 256, 20), (8, 512, 9), (4, 1024, 3), (48, 256, 17)][seed]
     want = carve_c.carve(*grid, fx.oracle_cams(cams3), masks3, frames3, color_cam=2)
     assert want["count"] > 0
     eng.set_grid(*grid)
@@ -166,7 +167,7 @@ def test_every_kernel_family_agrees_with_oracle(eng, seed):
     eng.upload_frame(2, frames3[2])
     eng.build_lut()
     try:
-        for opts in ({"lut_hier": 1}, {"lut_tile": 0}, {"fused_tile": 0}, {"fused_color_table": 1}, {"fused_boxes": 0}, {"fused_boxes": 0, "fused_f32box": 0},
+        for opts in ({"lut_hier": 1}, {"strips": 0}, {"cull": 0}, {"lut_tile": 0}, {"fused_tile": 0}, {"fused_color_table": 1}, {"fused_boxes": 0}, {"fused_boxes": 0, "fused_f32box": 0},
                      {"fused_boxes": 0, "fused_tile": 0}, {"lut_hier": 0}, {"lut_hier": 0, "first_kv": 4}, {"lut_hier": 1, "refine_b": 16, "refine_pair": 0},
                      {"reorder": 0}, {"fused_hier": 0}, {"refine_pair": 0}, {"emit_lanes": 0}, {"emit_busy": 2}, {"emit_busy": 2, "lut_tile": 0, "fused_tile": 0},
                      {"force_generic": 1}):
@@ -181,9 +182,9 @@ def test_every_kernel_family_agrees_with_oracle(eng, seed):
                 assert np.array_equal(eng.fetch_occupancy(), occ), (opts, mode)
                 assert int(np.bitwise_count(eng.pack_entries()[:, 0]).sum()) == want["count"], (opts, mode)
             for k in opts:
-                eng.set_option(k, {"lut_hier": 1, "lut_tile": 1, "fused_tile": 1, "fused_f32box": 1, "fused_boxes": 1, "fused_color_table": 0, "first_kv": 1, "refine_b": 8, "reorder": 1, "fused_hier": 1, "refine_pair": 1, "emit_lanes": 1, "emit_busy": 1, "force_generic": 0}[k])
+                eng.set_option(k, {"lut_hier": 1, "strips": 1, "cull": 1, "lut_tile": 1, "fused_tile": 1, "fused_f32box": 1, "fused_boxes": 1, "fused_color_table": 0, "first_kv": 1, "refine_b": 8, "reorder": 1, "fused_hier": 1, "refine_pair": 1, "emit_lanes": 1, "emit_busy": 1, "force_generic": 0}[k])
     finally:
-        for k, v in {"lut_hier": 1, "lut_tile": 1, "fused_tile": 1, "fused_f32box": 1, "fused_boxes": 1, "fused_color_table": 0, "first_kv": 1, "refine_b": 8, "reorder": 1, "fused_hier": 1, "refine_pair": 1, "emit_lanes": 1, "emit_busy": 1, "force_generic": 0}.items():
+        for k, v in {"lut_hier": 1, "strips": 1, "cull": 1, "lut_tile": 1, "fused_tile": 1, "fused_f32box": 1, "fused_boxes": 1, "fused_color_table": 0, "first_kv": 1, "refine_b": 8, "reorder": 1, "fused_hier": 1, "refine_pair": 1, "emit_lanes": 1, "emit_busy": 1, "force_generic": 0}.items():
             eng.set_option(k, v)
     with pytest.raises(Exception):
         eng.set_option("no_such_option", 1)
@@ -211,7 +212,7 @@ def test_hostile_cameras_inside_the_volume(eng, seed):
         cams3.append(cam)
     masks3 = [np.where(rng.random((H, W)) < 0.7, 255, 0).astype(np.uint8) for _ in range(3)]
     frames3 = [rng.integers(0, 256, (H, W, 3), dtype=np.uint8) for _ in range(3)]
-    grid = [(24, 64, 24), (16, 128, 12), (40, 64, 10), (9, 192, 9), (32, 64, 32), (12, 70, 12)][seed]
+    grid = [(24, 64, 24), (16, 128, 12), (40, 64, 10), (9, 192, 9), (32, 256, 18), (12, 70, 12)][seed]   # 5th: a strip shape
     oc = fx.oracle_cams(cams3)
     eng.set_grid(*grid)
     eng.set_cameras(cams3, H, W)

@@ -91,6 +91,11 @@ struct CarveParams {
     const uint64_t *tbox;       // [C][n_pad/64] pixel boxes of the tile words
     uint32_t tq;                // tile words per row quad = ny / 16
     uint32_t tile_whole;        // 64 % tq == 0: the 64 tile words of a wave are exactly one y-major group
+    // bricks of 16 x 16 x 16 voxels (4 row quads x 1 tile column x 16 layers = 64 tile words): culled per frame set
+    const uint64_t *kbox;       // [C][nbrick_pad] pixel boxes of the bricks (geometry only, built with tbox)
+    uint64_t *live;             // [2][nbrick_pad / 64]: bit per brick "may hold survivors", then "every voxel survives"; null: no culling
+    uint32_t nbx, nbz;          // bricks along x and (slab-local) z; along y there are tq
+    uint32_t nbrick_pad;        // bricks rounded up to 64
     const uint32_t *blockgrid;  // the frame set's header (block size, length, camera order) + per camera (crop[c].off):
                                 // any[ch][cws] then all[ch][cws], one bit per block of 2^shift x 2^shift pixels
     uint64_t *words;
@@ -377,6 +382,18 @@ __device__ __forceinline__ void tile_store(const CarveParams &p, uint32_t g, uin
     }
 }
 
+// Brick culling (k_cull): what the coarse level decided for the brick that holds tile word T.  live = the brick may hold
+// survivors; full = every voxel of it survives (inside every image, every block of every camera's box foreground).
+__device__ __forceinline__ void brick_bits(const CarveParams &p, uint64_t T, bool &live, bool &full)
+{
+    const uint32_t quad = (uint32_t)(T / p.tq), ty = (uint32_t)(T - (uint64_t)quad * p.tq), qpl = p.nx >> 2;
+    const uint32_t izl = quad / qpl, qx = quad - izl * qpl;
+    const uint32_t b = ((izl >> 4) * p.nbx + (qx >> 2)) * p.tq + ty;
+    const uint64_t lw = p.live[b >> 6], fw = p.live[(p.nbrick_pad >> 6) + (b >> 6)];
+    live = (lw >> (b & 63u)) & 1ull;
+    full = (fw >> (b & 63u)) & 1ull;
+}
+
 // HIER = false: refines the alive words k_lut_first left, cameras order[1..].
 // HIER = true : no first pass at all.  Coarse pass, lane = word: each camera's pixel box of the word
 //               against that camera's block grids (LDS).  Any camera with no foreground block in the
@@ -415,17 +432,37 @@ __device__ __forceinline__ void lut_refine_body(const CarveParams &p, uint32_t v
         uint64_t mine;
         uint32_t need = 0xffffffffu;                              // cameras (positions in order[]) still to test exactly
         if (HIER) {
-            // coarse pass, four cameras' boxes in flight at a time
-            bool cand = true;
+            const uint64_t j0 = (gw + lane) << 6;                 // TILE: n % 64 == 0, a word is whole or padding
+            bool cand = j0 < p.n, full = false;
+            if (TILE && p.live) {
+                // brick level first: what k_cull decided for the 16^3 brick around this word.  With ny == 1024 the wave's
+                // 64 words lie in the 64 bricks of one brick row: two scalar loads, and 4 of 5 groups end right here
+                if (p.tq == 64) {
+                    const uint32_t qpl = p.nx >> 2, izl = g / qpl, qx = g - izl * qpl;       // uniform
+                    const uint32_t bw = (izl >> 4) * p.nbx + (qx >> 2);
+                    const uint64_t lw = p.live[bw], fw = p.live[(p.nbrick_pad >> 6) + bw];
+                    full = cand && ((fw >> lane) & 1ull);
+                    cand = cand && ((lw >> lane) & 1ull);
+                } else if (cand) {
+                    bool lv;
+                    brick_bits(p, gw + lane, lv, full);
+                    cand = lv;
+                }
+                if (p.tile_whole && __ballot(cand) == 0) {        // dead group: count only (see below)
+                    if (lane == 0) p.groupcnt[g] = 0;
+                    continue;
+                }
+            }
+            // coarse pass, four cameras' boxes in flight at a time (words of a "full" brick need no look at all)
             need = 0;
-            for (uint32_t q0 = 0; q0 < p.C && __ballot(cand) != 0; q0 += 4) {
+            for (uint32_t q0 = 0; q0 < p.C && __ballot(cand && !full) != 0; q0 += 4) {
                 uint64_t bb[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    bb[k] = (q0 + k < p.C) ? (TILE ? p.tbox : p.bbox)[(size_t)ord(s_order, q0 + k) * nwords + gw + lane] : 0ull;
+                    bb[k] = (q0 + k < p.C && cand && !full) ? (TILE ? p.tbox : p.bbox)[(size_t)ord(s_order, q0 + k) * nwords + gw + lane] : 0ull;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    if (q0 + k < p.C && cand) {
+                    if (q0 + k < p.C && cand && !full) {
                         const uint32_t r = box_test(s_grid, load_gridcam(s_grid, ord(s_order, q0 + k)), bb[k], gshift);
                         cand = r != 0;
                         if (r == 1) need |= 1u << (q0 + k);
@@ -433,9 +470,8 @@ __device__ __forceinline__ void lut_refine_body(const CarveParams &p, uint32_t v
                 }
             }
             // a live word starts with every voxel of the slab alive (padding excluded)
-            const uint64_t j0 = (gw + lane) << 6;                 // TILE: n % 64 == 0, a word is whole or padding
             mine = 0;
-            if (cand && j0 < p.n) mine = (p.n - j0 >= 64) ? ~0ull : ((1ull << (p.n - j0)) - 1ull);
+            if (cand) mine = (p.n - j0 >= 64) ? ~0ull : ((1ull << (p.n - j0)) - 1ull);
             if (!cand) need = 0;
         } else {
             mine = next;
@@ -772,16 +808,28 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         const uint32_t ylast = TILE ? 15u : 63u;
         const double ya = p.ys[iy], yb = p.ys[iy + ylast < p.ny ? iy + ylast : p.ny - 1];
         uint32_t need = 0;                                       // cameras still to test voxel by voxel
+        bool full = false;
+        if (BOX == 2 && TILE && p.live) {                        // brick level first (see lut_refine_body)
+            if (cand) {
+                bool lv;
+                brick_bits(p, gw + lane, lv, full);
+                cand = lv;
+            }
+            if (p.tile_whole && __ballot(cand) == 0) {
+                if (lane == 0) p.groupcnt[g] = 0;
+                continue;
+            }
+        }
         if (BOX == 2) {
             const uint64_t nwords = p.n_pad >> 6;
-            for (uint32_t q0 = 0; q0 < p.C && __ballot(cand) != 0; q0 += 4) {      // four cameras' boxes in flight
+            for (uint32_t q0 = 0; q0 < p.C && __ballot(cand && !full) != 0; q0 += 4) {      // four cameras' boxes in flight
                 uint64_t bb[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    bb[k] = (q0 + k < p.C) ? (TILE ? p.tbox : p.bbox)[(size_t)ord(s_order, q0 + k) * nwords + gw + lane] : 0ull;
+                    bb[k] = (q0 + k < p.C && cand && !full) ? (TILE ? p.tbox : p.bbox)[(size_t)ord(s_order, q0 + k) * nwords + gw + lane] : 0ull;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    if (q0 + k < p.C && cand) {
+                    if (q0 + k < p.C && cand && !full) {
                         const uint32_t r = box_test(s_grid, load_gridcam(s_grid, ord(s_order, q0 + k)), bb[k], gshift);
                         cand = r != 0;
                         if (r == 1) need |= 1u << (q0 + k);
@@ -959,6 +1007,318 @@ __global__ __launch_bounds__(kBlock) void k_project(const CamDev cam, const doub
     project_point(cam, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], u, v);
     uv[2 * i] = u;
     uv[2 * i + 1] = v;
+}
+
+// ---------------------------------------------------------------- brick level
+// A brick is 16 x 16 x 16 voxels = 4 row quads x 1 tile column x 16 layers = 64 tile words; brick number
+// b = (bz * nbx + bx) * tq + by, so the 64 bricks of one brick row along y are one u64 of the bit maps.
+// k_brick_boxes (once per grid / slab / camera set): a brick's pixel box per camera = union of its words' boxes;
+// the "every voxel inside the image" flag survives only if every word has it.
+__global__ __launch_bounds__(kBlock) void k_brick_boxes(const CarveParams p, const uint64_t *__restrict__ tbox,
+                                                        uint64_t *__restrict__ kbox)
+{
+    const uint32_t b = blockIdx.x * kBlock + threadIdx.x;
+    if (b >= p.nbrick_pad) return;
+    const uint32_t qpl = p.nx >> 2, nzl = (uint32_t)(p.n / ((uint64_t)p.nx * p.ny));
+    const uint32_t col = b / p.tq, by = b - col * p.tq, bz = col / p.nbx, bx = col - bz * p.nbx;
+    const uint64_t nwords = p.n_pad >> 6;
+    for (uint32_t c = 0; c < p.C; ++c) {
+        uint32_t u0 = 0xffffu, v0 = 0xffffu, u1 = 0, v1 = 0;
+        bool inside = true, any = false;
+        if (bz < p.nbz) {
+            for (uint32_t z = 16 * bz; z < 16 * bz + 16 && z < nzl; ++z)
+                for (uint32_t qx = 4 * bx; qx < 4 * bx + 4 && qx < qpl; ++qx) {
+                    const uint64_t w = tbox[(size_t)c * nwords + ((uint64_t)z * qpl + qx) * p.tq + by];
+                    if (w == kEmptyBox) { inside = false; continue; }
+                    any = true;
+                    inside = inside && (w >> 63);
+                    const uint32_t a0 = (uint32_t)(w & 0xffffu), a1 = (uint32_t)((w >> 16) & 0xffffu);
+                    const uint32_t a2 = (uint32_t)((w >> 32) & 0xffffu), a3 = (uint32_t)((w >> 48) & 0x7fffu);
+                    u0 = a0 < u0 ? a0 : u0; v0 = a1 < v0 ? a1 : v0; u1 = a2 > u1 ? a2 : u1; v1 = a3 > v1 ? a3 : v1;
+                }
+        }
+        kbox[(size_t)c * p.nbrick_pad + b] = !any ? kEmptyBox
+            : ((uint64_t)u0 | ((uint64_t)v0 << 16) | ((uint64_t)u1 << 32) | ((uint64_t)v1 << 48) | (inside ? kBoxAllInside : 0ull));
+    }
+}
+
+// k_cull (every frame set, in front of the hierarchical carve): lane = brick, every camera's brick box against that
+// camera's block grids (LDS).  No foreground block in some camera's box: no voxel of the brick can survive (exact: the box
+// contains the pixel of every voxel of every word of the brick) -- its 64 words are never looked at.  Every block of every
+// camera's box foreground and every voxel inside every image: all 4096 voxels survive, equally without a look.
+__global__ __launch_bounds__(kBlock) void k_cull(const CarveParams p)
+{
+    extern __shared__ uint32_t s_grid[];
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.blockgrid);
+        uint4 *dst = reinterpret_cast<uint4 *>(s_grid);
+        const uint32_t gwords = hdr_u32(p.blockgrid, kHdrWords);
+        for (uint32_t i = threadIdx.x; i < (gwords + 3) / 4; i += kBlock) dst[i] = src[i];
+        __syncthreads();
+    }
+    __shared__ uint32_t s_order[kMaxCameras];
+    stage_order(s_grid, p.C, s_order);
+    const uint32_t gshift = hdr_u32(s_grid, kHdrShift);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
+    const uint32_t nwaves = gridDim.x * (kBlock / 64);
+    const uint32_t nw = p.nbrick_pad >> 6;
+    for (uint32_t w = wave0; w < nw; w += nwaves) {
+        const uint32_t b = w * 64 + lane;
+        bool cand = true, full = true;
+        for (uint32_t q0 = 0; q0 < p.C && __ballot(cand) != 0; q0 += 4) {
+            uint64_t bb[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                bb[k] = (q0 + k < p.C && cand) ? p.kbox[(size_t)ord(s_order, q0 + k) * p.nbrick_pad + b] : 0ull;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (q0 + k < p.C && cand) {
+                    const uint32_t r = box_test(s_grid, load_gridcam(s_grid, ord(s_order, q0 + k)), bb[k], gshift);
+                    cand = r != 0;
+                    full = full && r == 2;
+                }
+            }
+        }
+        const uint64_t lw = __ballot(cand), fw = __ballot(cand && full);
+        if (lane == 0) { p.live[w] = lw; p.live[nw + w] = fw; }
+    }
+}
+
+// ---------------------------------------------------------------- strips
+// The default carve for ny in {256, 512, 1024} (groups of 4096 consecutive voxels then lie inside one brick column).
+// Culling whole bricks leaves a wave of the group-wise kernels with a handful of live lanes: the hull crosses a
+// 1024-voxel line of y in a few bricks only.  So the work is re-cut into STRIPS: one row quad x 64 y x the 16 layers of
+// a brick row = 64 tile words = 4 bricks along y; lane (l, w) holds the word of layer l, tile column w.  A strip with a
+// live brick has at least a quarter of its lanes busy, an interior one all of them.
+//
+//  k_cull_strips   k_cull plus: zeroes the survivor counts of all groups, and appends, for every brick COLUMN with a live
+//                  brick, all its strips to a list (one atomic add per wave): {strip number, live bits, full bits of its 4
+//                  bricks}.  Strips of columns without any live brick are never touched again -- their groups keep count 0
+//                  and nobody reads their words.
+//  k_carve_strips  one wave per listed strip: word boxes against the block grids for the lanes of live, not-full bricks;
+//                  exact per-voxel test for the undecided words (LUT: table entries; else float64 projection), eight words
+//                  at a time; the four tile words of a layer are turned into four y-major words inside their lane quad
+//                  (DPP broadcasts) and stored, their survivors added to the group's count.  A listed strip without a live
+//                  brick stores zeros: every word of a group that can have survivors is valid afterwards.
+struct StripList {
+    uint32_t *entries;          // strip number | live nibble << 20 | full nibble << 24
+    uint32_t *counters;         // [2], used alternately: the launch that fills one zeroes the other
+    uint32_t parity;
+};
+
+__global__ __launch_bounds__(kBlock) void k_cull_strips(const CarveParams p, const StripList sl, uint32_t ngroups)
+{
+    extern __shared__ uint32_t s_grid[];
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.blockgrid);
+        uint4 *dst = reinterpret_cast<uint4 *>(s_grid);
+        const uint32_t gwords = hdr_u32(p.blockgrid, kHdrWords);
+        for (uint32_t i = threadIdx.x; i < (gwords + 3) / 4; i += kBlock) dst[i] = src[i];
+        __syncthreads();
+    }
+    __shared__ uint32_t s_order[kMaxCameras];
+    stage_order(s_grid, p.C, s_order);
+    if (blockIdx.x == 0 && threadIdx.x == 0) sl.counters[sl.parity ^ 1u] = 0;
+    const uint32_t gshift = hdr_u32(s_grid, kHdrShift);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
+    const uint32_t nwaves = gridDim.x * (kBlock / 64);
+    const uint32_t nw = p.nbrick_pad >> 6, qpl = p.nx >> 2;
+    const uint32_t nbricks = p.nbx * p.tq * p.nbz;
+    for (uint32_t i = (blockIdx.x * kBlock + threadIdx.x); i < ngroups; i += gridDim.x * kBlock) p.groupcnt[i] = 0;
+    for (uint32_t w = wave0; w < nw; w += nwaves) {
+        const uint32_t b = w * 64 + lane;
+        bool cand = true, full = true;
+        for (uint32_t q0 = 0; q0 < p.C && __ballot(cand) != 0; q0 += 4) {
+            uint64_t bb[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                bb[k] = (q0 + k < p.C && cand) ? p.kbox[(size_t)ord(s_order, q0 + k) * p.nbrick_pad + b] : 0ull;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (q0 + k < p.C && cand) {
+                    const uint32_t r = box_test(s_grid, load_gridcam(s_grid, ord(s_order, q0 + k)), bb[k], gshift);
+                    cand = r != 0;
+                    full = full && r == 2;
+                }
+            }
+        }
+        const uint64_t lw = __ballot(cand), fw = __ballot(cand && full);
+        if (lw == 0) continue;                                    // (wave-uniform)
+        // lane (j, q): the strip of tile columns 4j .. 4j+3 of this wave's bricks, row quad q of its brick column
+        const uint32_t j = lane >> 2, q = lane & 3u;
+        const uint32_t b0 = w * 64 + 4 * j;
+        const uint32_t col = b0 / p.tq, by0 = b0 - col * p.tq;   // tq divides 64: a column never straddles two waves
+        const uint64_t colbits = p.tq == 64 ? lw : (lw >> ((col * p.tq) & 63u)) & ((1ull << p.tq) - 1ull);
+        const uint32_t bz = col / p.nbx, bx = col - bz * p.nbx;
+        const bool want = b0 < nbricks && colbits != 0 && 4 * bx + q < qpl;
+        const uint32_t entry = ((col * 4 + q) * (p.tq >> 2) + (by0 >> 2)) | ((uint32_t)((lw >> (4 * j)) & 15ull) << 20) |
+                               ((uint32_t)((fw >> (4 * j)) & 15ull) << 24);
+        const uint64_t wm = __ballot(want);
+        uint32_t base = 0;
+        if (lane == 0 && wm) base = atomicAdd(&sl.counters[sl.parity], (uint32_t)__popcll(wm));
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (want) sl.entries[base + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull))] = entry;
+    }
+}
+
+__device__ __forceinline__ uint64_t quad_bcast64(uint64_t v, int q)       // value of lane q of this lane's quad
+{
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    switch (q) {
+    case 0: lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)lo, 0x00, 0xf, 0xf, true); hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)hi, 0x00, 0xf, 0xf, true); break;
+    case 1: lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)lo, 0x55, 0xf, 0xf, true); hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)hi, 0x55, 0xf, 0xf, true); break;
+    case 2: lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)lo, 0xaa, 0xf, 0xf, true); hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)hi, 0xaa, 0xf, 0xf, true); break;
+    default: lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)lo, 0xff, 0xf, 0xf, true); hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)hi, 0xff, 0xf, 0xf, true); break;
+    }
+    return ((uint64_t)hi << 32) | lo;
+}
+
+template <bool LUT>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_carve_strips(const CarveParams p, const StripList sl)
+{
+    constexpr int B = 8;
+    extern __shared__ uint32_t s_grid[];
+    if (blockIdx.x * (kBlock / 64) >= hdr_u32(sl.counters, sl.parity)) return;      // fewer strips than waves launched
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.blockgrid);
+        uint4 *dst = reinterpret_cast<uint4 *>(s_grid);
+        const uint32_t gwords = hdr_u32(p.blockgrid, kHdrWords);
+        for (uint32_t i = threadIdx.x; i < (gwords + 3) / 4; i += kBlock) dst[i] = src[i];
+        __syncthreads();
+    }
+    __shared__ uint32_t s_order[kMaxCameras];
+    stage_order(s_grid, p.C, s_order);
+    const uint32_t gshift = hdr_u32(s_grid, kHdrShift);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
+    const uint32_t nwaves = gridDim.x * (kBlock / 64);
+    const uint32_t nlist = hdr_u32(sl.counters, sl.parity);
+    const uint32_t qpl = p.nx >> 2, nzl = (uint32_t)(p.n / ((uint64_t)p.nx * p.ny));
+    const uint32_t cps = p.tq >> 2, lcps = (uint32_t)__builtin_ctz(cps);     // strips per row quad: a power of two (tq divides 64)
+    const uint64_t nwords = p.n_pad >> 6;
+    const uint32_t l = lane >> 2, w = lane & 3u;
+    for (uint32_t t = wave0; t < nlist; t += nwaves) {
+        const uint32_t e = hdr_u32(sl.entries, t);
+        const uint32_t sn = e & 0xfffffu, nib = (e >> 20) & 15u, fnib = (e >> 24) & 15u;
+        const uint32_t k = sn & (cps - 1u), cq = sn >> lcps, q = cq & 3u, col = cq >> 2;
+        const uint32_t bz = col / p.nbx, bx = col - bz * p.nbx, qx = 4 * bx + q;                 // all wave-uniform
+        const uint32_t izl = 16 * bz + l;
+        const bool valid = izl < nzl;
+        const uint64_t T = ((uint64_t)(valid ? izl : 0u) * qpl + qx) * p.tq + 4 * k + w;      // my tile word
+        bool cand = valid && ((nib >> w) & 1u);
+        const bool full = (fnib >> w) & 1u;
+        uint32_t need = 0;
+        // ---- word level: four cameras' boxes in flight (words of a "full" brick need no look at all)
+        for (uint32_t q0 = 0; q0 < p.C && __ballot(cand && !full) != 0; q0 += 4) {
+            uint64_t bb[4];
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4)
+                bb[c4] = (q0 + c4 < p.C && cand && !full) ? p.tbox[(size_t)ord(s_order, q0 + c4) * nwords + T] : 0ull;
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                if (q0 + c4 < p.C && cand && !full) {
+                    const uint32_t r = box_test(s_grid, load_gridcam(s_grid, ord(s_order, q0 + c4)), bb[c4], gshift);
+                    cand = r != 0;
+                    if (r == 1) need |= 1u << (q0 + c4);
+                }
+            }
+        }
+        uint64_t mine = cand ? ~0ull : 0ull;
+        if (!cand) need = 0;
+        // ---- voxel level, lanes = the 64 voxels of an undecided tile word (4 x-rows x 16 y)
+        const uint32_t Tlo = (uint32_t)T, Thi = (uint32_t)(T >> 32);
+        uint64_t nz = __ballot(mine != 0 && need != 0);
+        if (LUT) {
+            while (nz != 0) {                                     // wave-uniform; B words at a time so that the dependent loads overlap
+                uint32_t li[B], nd[B];
+                uint64_t Tb[B];
+                uint32_t alive = 0;
+#pragma unroll
+                for (int b = 0; b < B; ++b) {
+                    li[b] = 64; nd[b] = 0; Tb[b] = 0;
+                    if (nz != 0) {
+                        li[b] = (uint32_t)__builtin_ctzll(nz);
+                        nz &= nz - 1;
+                        nd[b] = (uint32_t)__builtin_amdgcn_readlane((int)need, (int)li[b]);
+                        Tb[b] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)Thi, (int)li[b]) << 32) |
+                                (uint32_t)__builtin_amdgcn_readlane((int)Tlo, (int)li[b]);
+                        alive |= 1u << b;
+                    }
+                }
+                uint32_t ndany = 0;
+#pragma unroll
+                for (int b = 0; b < B; ++b) ndany |= nd[b];
+                for (uint32_t qq = 0; qq < p.C; qq += 2) {        // two cameras' entries per dependent round trip
+                    if (((ndany >> qq) & 3u) == 0) continue;
+                    const bool two = qq + 1 < p.C;
+                    const uint32_t c = ord(s_order, qq), c2 = ord(s_order, two ? qq + 1 : qq);
+                    const int32_t *__restrict__ L1 = p.lut_tile + (size_t)c * p.n_pad + lane;
+                    const int32_t *__restrict__ L2 = p.lut_tile + (size_t)c2 * p.n_pad + lane;
+                    const uint32_t *__restrict__ mb = p.maskbits + (size_t)c * p.mwords;
+                    const uint32_t *__restrict__ mb2 = p.maskbits + (size_t)c2 * p.mwords;
+                    int32_t off[B], off2[B];
+                    uint32_t mw[B], mw2[B];
+#pragma unroll
+                    for (int b = 0; b < B; ++b) {                 // a camera outside the word's mask counts as passed
+                        const bool t1 = ((nd[b] >> qq) & 1u) && ((alive >> b) & 1u);
+                        const bool t2 = two && ((nd[b] >> (qq + 1)) & 1u) && ((alive >> b) & 1u);
+                        off[b] = t1 ? L1[Tb[b] * 64] : -2;
+                        off2[b] = t2 ? L2[Tb[b] * 64] : -2;
+                    }
+#pragma unroll
+                    for (int b = 0; b < B; ++b) {
+                        mw[b] = (off[b] >= 0) ? mb[(uint32_t)off[b] >> 5] : (off[b] == -2 ? ~0u : 0u);
+                        mw2[b] = (off2[b] >= 0) ? mb2[(uint32_t)off2[b] >> 5] : (off2[b] == -2 ? ~0u : 0u);
+                    }
+#pragma unroll
+                    for (int b = 0; b < B; ++b)
+                        if (!((mw[b] >> ((uint32_t)off[b] & 31u)) & (mw2[b] >> ((uint32_t)off2[b] & 31u)) & 1u)) alive &= ~(1u << b);
+                    if (__ballot(alive != 0) == 0) break;
+                }
+#pragma unroll
+                for (int b = 0; b < B; ++b) {
+                    if (li[b] < 64) {
+                        const uint64_t nb = __ballot((alive >> b) & 1u);
+                        if (lane == li[b]) mine = nb;
+                    }
+                }
+            }
+        } else {
+            while (nz != 0) {                                     // table-free: exact float64 projection, one word at a time
+                const uint32_t wl = (uint32_t)__builtin_ctzll(nz);
+                nz &= nz - 1;
+                const uint32_t nd = (uint32_t)__builtin_amdgcn_readlane((int)need, (int)wl);
+                const uint32_t wzl = 16 * bz + (wl >> 2), wty = 4 * k + (wl & 3u);               // that lane's layer and tile column
+                const double VX = p.xs[4 * qx + (lane >> 4)], VY = p.ys[16 * wty + (lane & 15u)], VZ = p.zs[p.z0 + wzl];
+                bool alive = true;
+                for (uint32_t qq = 0; qq < p.C; ++qq) {
+                    if (!((nd >> qq) & 1u)) continue;             // decided for the whole word by its box
+                    const uint32_t c = ord(s_order, qq);
+                    if (alive) {
+                        double u, v;
+                        project_point(p.cam[c], VX, VY, VZ, u, v);
+                        const int32_t off = pixel_offset(u, v, p.H, p.W);
+                        alive = off >= 0 && mask_bit(p.maskbits + (size_t)c * p.mwords, off);
+                    }
+                    if (__ballot(alive) == 0) break;
+                }
+                const uint64_t nb = __ballot(alive);
+                if (lane == wl) mine = nb;
+            }
+        }
+        // ---- the four tile words of a layer -> the four y-major words (rows) of that layer's 64 y, inside the lane quad
+        uint64_t out = 0;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) out |= ((quad_bcast64(mine, qd) >> (16 * w)) & 0xffffull) << (16 * qd);
+        if (valid) {
+            const uint64_t lw = ((uint64_t)izl * p.nx + 4 * qx + w) * (p.ny >> 6) + k;          // lane (l, w) now holds row w
+            p.words[lw] = out;
+            const uint32_t pc = (uint32_t)__popcll(out);
+            if (pc) atomicAdd(&p.groupcnt[lw >> 6], pc);
+        }
+    }
 }
 
 // ---------------------------------------------------------------- per-frame preparation

@@ -191,6 +191,14 @@ struct vc_ctx {
     DevBuf<uint64_t> d_bbox;         // [C][n_pad/64] per-word pixel boxes (built with the LUT)
     DevBuf<int32_t> d_lut_tile;      // the table in tile order (words of 4 x-rows x 16 y), when the grid allows
     DevBuf<uint64_t> d_tbox;         // pixel boxes of the tile words
+    DevBuf<uint64_t> d_kbox;         // pixel boxes of the 16^3 bricks (64 tile words each)
+    DevBuf<uint64_t> d_live;         // per frame set: bit per brick "may hold survivors" | "all voxels survive" (k_cull)
+    DevBuf<uint32_t> d_strips;       // per frame set: the strips of the brick columns with a live brick (k_cull_strips) + 2 counters
+    uint32_t strip_parity = 0;
+    int strips = 1;                  // carve by strips where the grid shape allows (ny in {256, 512, 1024})
+    int strip_blocks_per_cu = 8;
+    bool kbox_valid = false;
+    int cull = 1;                    // hierarchical kernels on tile words: cull whole bricks first
     bool tile_valid = false;
     bool bbox_valid = false, tbox_valid = false;   // boxes match the grid, slab and cameras (also built without a table)
     int grid_lds_kb = 16;            // LDS budget of a frame set's block grids (picks their resolution at upload)
@@ -305,6 +313,8 @@ void release(DevBuf<T> &b)
         if (rc_ != VC_OK) return rc_; \
     } while (0)
 
+uint32_t grid_for(uint64_t n);
+
 void fill_params(const vc_ctx *ctx, CarveParams &p)
 {
     memset(&p, 0, sizeof p);
@@ -319,6 +329,28 @@ void fill_params(const vc_ctx *ctx, CarveParams &p)
     p.bbox = ctx->d_bbox.ptr;
     p.lut_tile = ctx->d_lut_tile.ptr; p.tbox = ctx->d_tbox.ptr; p.tq = ctx->ny / 16;
     p.tile_whole = (p.tq != 0 && 64 % p.tq == 0) ? 1u : 0u;
+    p.kbox = ctx->d_kbox.ptr;
+    p.live = nullptr;                                            // set by the launches that cull
+    p.nbx = ((ctx->nx >> 2) + 3) / 4;
+    p.nbz = (ctx->z1 - ctx->z0 + 15) / 16;
+    p.nbrick_pad = (uint32_t)(((uint64_t)p.nbx * p.tq * p.nbz + 63) / 64 * 64);
+}
+
+// The bricks' pixel boxes from the tile words' (once per grid / slab / camera set, right behind the tile boxes).
+int build_brick_boxes(vc_ctx *ctx)
+{
+    CarveParams p;
+    fill_params(ctx, p);
+    ctx->kbox_valid = false;
+    if (p.nbrick_pad == 0) return VC_OK;
+    VC_TRY(ensure(ctx, ctx->d_kbox, (size_t)p.nbrick_pad * ctx->C));
+    VC_TRY(ensure(ctx, ctx->d_live, (size_t)(p.nbrick_pad / 64) * 2));
+    p.kbox = ctx->d_kbox.ptr;
+    hipLaunchKernelGGL(k_brick_boxes, dim3(grid_for(p.nbrick_pad)), dim3(kBlock), 0, ctx->stream, p, (const uint64_t *)ctx->d_tbox.ptr,
+                       ctx->d_kbox.ptr);
+    VC_HIP(ctx, hipGetLastError());
+    ctx->kbox_valid = true;
+    return VC_OK;
 }
 
 constexpr int VC_MAX_RANKS = 64;
@@ -328,6 +360,36 @@ constexpr int kSub = 4;                    // 64-voxel sub-chunks per wavefront 
 constexpr size_t kLdsBytes = 160 * 1024;   // LDS per CU on gfx950
 constexpr size_t kMaxFirstLds = 64 * 1024; // static limit of one workgroup's dynamic LDS without opt-in
 constexpr uint32_t kEstimateSamples = 1u << 16;
+
+// Grid shapes the strip kernels take: a group of 4096 consecutive voxels must lie inside one brick column (see k_carve_strips).
+bool strip_shape(const vc_ctx *ctx, const CarveParams &p)
+{
+    if (!ctx->strips || !ctx->cull || !ctx->kbox_valid) return false;
+    if (ctx->ny != 256 && ctx->ny != 512 && ctx->ny != 1024) return false;
+    if (ctx->nx % (4096u / ctx->ny) != 0 || ctx->nx % 4 != 0) return false;
+    return (uint64_t)p.nbx * p.tq * p.nbz <= (1u << 20);
+}
+
+template <bool LUT>
+int launch_strips(vc_ctx *ctx, CarveParams &p, size_t lds, uint32_t ngroups)
+{
+    const size_t need = (size_t)p.nbrick_pad + 64 + 2;
+    if (ctx->d_strips.cap < need) {
+        VC_TRY(ensure(ctx, ctx->d_strips, need));
+        VC_HIP(ctx, hipMemsetAsync(ctx->d_strips.ptr, 0, 2 * sizeof(uint32_t), ctx->stream));      // both counters
+        ctx->strip_parity = 0;
+    }
+    StripList sl;
+    sl.counters = ctx->d_strips.ptr;
+    sl.entries = ctx->d_strips.ptr + 2;
+    sl.parity = (ctx->strip_parity ^= 1u);
+    p.live = ctx->d_live.ptr;
+    const uint32_t cw = p.nbrick_pad / 256;
+    hipLaunchKernelGGL(k_cull_strips, dim3(cw < 1 ? 1 : (cw > 1024 ? 1024 : cw)), dim3(kBlock), lds, ctx->stream, p, sl, ngroups);
+    hipLaunchKernelGGL((k_carve_strips<LUT>), dim3(256u * (uint32_t)ctx->strip_blocks_per_cu), dim3(kBlock), lds, ctx->stream, p, sl);
+    VC_HIP(ctx, hipGetLastError());
+    return VC_OK;
+}
 
 int slot_at(vc_ctx *ctx, uint32_t slot, Slot **out)
 {
@@ -513,6 +575,7 @@ int ensure_boxes(vc_ctx *ctx, bool tile)
     else hipLaunchKernelGGL(k_build_lut<false>, dim3(grid_for(n_pad)), dim3(kBlock), 0, ctx->stream, p, (int32_t *)nullptr, buf.ptr);
     VC_HIP(ctx, hipGetLastError());
     (tile ? ctx->tbox_valid : ctx->bbox_valid) = true;
+    if (tile) VC_TRY(build_brick_boxes(ctx));
     return VC_OK;
 }
 
@@ -723,7 +786,7 @@ int vc_destroy(vc_ctx *ctx)
         if (s.e_up) (void)hipEventDestroy(s.e_up);
     }
     for (int k = 0; k < 2; ++k) if (ctx->ev_h[k]) (void)hipEventDestroy(ctx->ev_h[k]);
-    release(ctx->d_axes); release(ctx->d_morph); release(ctx->d_lut); release(ctx->d_bbox); release(ctx->d_lut_tile); release(ctx->d_tbox);
+    release(ctx->d_axes); release(ctx->d_morph); release(ctx->d_lut); release(ctx->d_bbox); release(ctx->d_lut_tile); release(ctx->d_tbox); release(ctx->d_kbox); release(ctx->d_live); release(ctx->d_strips);
     for (StepBuf &b : ctx->sb) {
         release(b.words); release(b.groupcnt); release(b.groupoff); release(b.blocksum); release(b.blockoff); release(b.records);
         release(b.ent); release(b.mine); release(b.counts);
@@ -784,7 +847,7 @@ int vc_set_grid(vc_ctx *ctx, uint32_t nx, uint32_t ny, uint32_t nz, const double
     VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->have_grid = true;
     for (Slot &sl : ctx->slots) sl.grids_valid = false;       // the camera order was sampled on the old geometry
-    ctx->lut_valid = false; ctx->bbox_valid = false; ctx->tbox_valid = false; ctx->carved = false; ctx->gathered = false; ctx->viewmask_valid = false;
+    ctx->lut_valid = false; ctx->bbox_valid = false; ctx->tbox_valid = false; ctx->kbox_valid = false; ctx->carved = false; ctx->gathered = false; ctx->viewmask_valid = false;
     ctx->lut_color_cam = -1; ctx->packed = false;
     return VC_OK;
 }
@@ -797,7 +860,7 @@ int vc_set_slab(vc_ctx *ctx, uint32_t z0, uint32_t z1)
     if (z0 > z1 || z1 > ctx->nz) return fail(ctx, VC_ERR_ARG, "slab [%u,%u) outside [0,%u]", z0, z1, ctx->nz);
     ctx->z0 = z0; ctx->z1 = z1;
     for (Slot &sl : ctx->slots) sl.grids_valid = false;
-    ctx->lut_valid = false; ctx->bbox_valid = false; ctx->tbox_valid = false; ctx->carved = false; ctx->gathered = false; ctx->viewmask_valid = false;
+    ctx->lut_valid = false; ctx->bbox_valid = false; ctx->tbox_valid = false; ctx->kbox_valid = false; ctx->carved = false; ctx->gathered = false; ctx->viewmask_valid = false;
     ctx->packed = false;
     return VC_OK;
 }
@@ -841,7 +904,7 @@ int vc_set_cameras(vc_ctx *ctx, uint32_t C, const double *K9, const double *dist
         for (Slot &s : ctx->slots) release_slot(s);
     }
     for (Slot &sl : ctx->slots) sl.grids_valid = false;
-    ctx->lut_valid = false; ctx->bbox_valid = false; ctx->tbox_valid = false; ctx->carved = false; ctx->gathered = false; ctx->viewmask_valid = false;
+    ctx->lut_valid = false; ctx->bbox_valid = false; ctx->tbox_valid = false; ctx->kbox_valid = false; ctx->carved = false; ctx->gathered = false; ctx->viewmask_valid = false;
     ctx->lut_color_cam = -1; ctx->packed = false;
     return VC_OK;
 }
@@ -968,6 +1031,7 @@ int vc_build_lut(vc_ctx *ctx)
             VC_HIP(ctx, hipGetLastError());
             ctx->tile_valid = true;
             ctx->tbox_valid = true;
+            VC_TRY(build_brick_boxes(ctx));
         }
         VC_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
         VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1103,7 +1167,17 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
                     VC_HIP(ctx, hipMemsetAsync(sb.groupcnt.ptr, 0, sizeof(uint32_t) * ngroups, ctx->stream));
                     sb.sparse_words = false;
                 }
-                hipLaunchKernelGGL((k_lut_refine<8, true, true, true>), rgrid, block, lds, ctx->stream, p);
+                if (strip_shape(ctx, p)) {
+                    sb.sparse_words = true;              // (k_cull_strips zeroes every group's count itself)
+                    VC_TRY(launch_strips<true>(ctx, p, lds, ngroups));
+                } else {
+                    if (ctx->cull && ctx->kbox_valid) {
+                        p.live = ctx->d_live.ptr;
+                        const uint32_t cw = p.nbrick_pad / 256;
+                        hipLaunchKernelGGL(k_cull, dim3(cw < 1 ? 1 : (cw > 1024 ? 1024 : cw)), block, lds, ctx->stream, p);
+                    }
+                    hipLaunchKernelGGL((k_lut_refine<8, true, true, true>), rgrid, block, lds, ctx->stream, p);
+                }
             }
             else if (ctx->refine_pair) hipLaunchKernelGGL((k_lut_refine<8, true, true>), rgrid, block, lds, ctx->stream, p);
             else if (ctx->refine_b == 8) hipLaunchKernelGGL((k_lut_refine<8, true, false>), rgrid, block, lds, ctx->stream, p);
@@ -1146,7 +1220,18 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
                 if (ctx->fused_boxes) {
                     VC_TRY(ensure_boxes(ctx, true));
                     p.tbox = ctx->d_tbox.ptr;
-                    hipLaunchKernelGGL((k_carve_fused_hier<true, 2>), rgrid, block, lds, ctx->stream, p);
+                    p.kbox = ctx->d_kbox.ptr;
+                    if (strip_shape(ctx, p)) {
+                        sb.sparse_words = true;
+                        VC_TRY(launch_strips<false>(ctx, p, lds, ngroups));
+                    } else {
+                        if (ctx->cull && ctx->kbox_valid) {
+                            p.live = ctx->d_live.ptr;
+                            const uint32_t cw = p.nbrick_pad / 256;
+                            hipLaunchKernelGGL(k_cull, dim3(cw < 1 ? 1 : (cw > 1024 ? 1024 : cw)), block, lds, ctx->stream, p);
+                        }
+                        hipLaunchKernelGGL((k_carve_fused_hier<true, 2>), rgrid, block, lds, ctx->stream, p);
+                    }
                 }
                 else if (ctx->fused_f32box) hipLaunchKernelGGL((k_carve_fused_hier<true, 1>), rgrid, block, lds, ctx->stream, p);
                 else hipLaunchKernelGGL((k_carve_fused_hier<true, 0>), rgrid, block, lds, ctx->stream, p);
@@ -1408,6 +1493,9 @@ int vc_set_option(vc_ctx *ctx, const char *name, int value)
     else if (k == "emit_lanes") ctx->emit_lanes = value != 0;
     else if (k == "overlap") ctx->overlap = value != 0;
     else if (k == "timing_detail") ctx->timing_detail = value != 0;
+    else if (k == "cull") ctx->cull = value != 0;
+    else if (k == "strips") ctx->strips = value != 0;
+    else if (k == "strip_blocks_per_cu" && value >= 1 && value <= 64) ctx->strip_blocks_per_cu = value;
     else if (k == "emit_busy" && value >= 0 && value <= 2) ctx->emit_busy = value;          // 0 never, 1 large grids, 2 always
     else if (k == "emit_waves_per_cu" && value >= 4 && value <= 1024) ctx->emit_waves_per_cu = value;
     else if (k == "lut_tile") ctx->lut_tile = value != 0;
