@@ -185,6 +185,10 @@ int vc_fetch_occupancy(vc_ctx *ctx, uint8_t *bits);
  * Unknown names or out-of-range values return VC_ERR_ARG. */
 int vc_set_option(vc_ctx *ctx, const char *name, int value);
 int vc_timing(vc_ctx *ctx, vc_timing_t *out);
+/* Diagnostics of the last brick-pipeline carve (scripts/, DESIGN figures): out[0] bricks listed for a look at their words,
+ * out[1] bricks that may hold survivors, out[2] bricks whose voxels all survive, out[3] bricks of the slab, out[4] brick
+ * columns listed, out[5] tile words that took the per-voxel test; the rest 0. */
+int vc_debug_counters(vc_ctx *ctx, uint64_t out[8]);
 int vc_timing_reset(vc_ctx *ctx);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI (no reference counterpart) ---- */

@@ -73,6 +73,7 @@ SIGNATURES = {
     "vc_fetch_occupancy": (ctypes.c_int, [c_ctx, c_u8p]),
     "vc_set_option": (ctypes.c_int, [c_ctx, ctypes.c_char_p, ctypes.c_int]),
     "vc_timing": (ctypes.c_int, [c_ctx, ctypes.POINTER(VcTiming)]),
+    "vc_debug_counters": (ctypes.c_int, [c_ctx, c_u64p]),
     "vc_timing_reset": (ctypes.c_int, [c_ctx]),
     "vc_comm_unique_id": (ctypes.c_int, [c_u8p]),
     "vc_comm_init": (ctypes.c_int, [c_ctx, ctypes.c_int, ctypes.c_int, c_u8p]),

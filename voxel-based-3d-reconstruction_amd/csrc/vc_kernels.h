@@ -106,6 +106,7 @@ struct CarveParams {
     uint32_t nx, ny, nz, z0;
     uint32_t C, H, W, mwords;
     uint32_t min_views;
+    uint32_t dbg;               // experiments only (vc_set_option("dbg", ...)): 1 = skip the voxel level, 2 = skip the word level
     CamDev cam[kMaxCameras];
 };
 
@@ -1012,36 +1013,7 @@ __global__ __launch_bounds__(kBlock) void k_project(const CamDev cam, const doub
 // ---------------------------------------------------------------- brick level
 // A brick is 16 x 16 x 16 voxels = 4 row quads x 1 tile column x 16 layers = 64 tile words; brick number
 // b = (bz * nbx + bx) * tq + by, so the 64 bricks of one brick row along y are one u64 of the bit maps.
-// k_brick_boxes (once per grid / slab / camera set): a brick's pixel box per camera = union of its words' boxes;
-// the "every voxel inside the image" flag survives only if every word has it.
-__global__ __launch_bounds__(kBlock) void k_brick_boxes(const CarveParams p, const uint64_t *__restrict__ tbox,
-                                                        uint64_t *__restrict__ kbox)
-{
-    const uint32_t b = blockIdx.x * kBlock + threadIdx.x;
-    if (b >= p.nbrick_pad) return;
-    const uint32_t qpl = p.nx >> 2, nzl = (uint32_t)(p.n / ((uint64_t)p.nx * p.ny));
-    const uint32_t col = b / p.tq, by = b - col * p.tq, bz = col / p.nbx, bx = col - bz * p.nbx;
-    const uint64_t nwords = p.n_pad >> 6;
-    for (uint32_t c = 0; c < p.C; ++c) {
-        uint32_t u0 = 0xffffu, v0 = 0xffffu, u1 = 0, v1 = 0;
-        bool inside = true, any = false;
-        if (bz < p.nbz) {
-            for (uint32_t z = 16 * bz; z < 16 * bz + 16 && z < nzl; ++z)
-                for (uint32_t qx = 4 * bx; qx < 4 * bx + 4 && qx < qpl; ++qx) {
-                    const uint64_t w = tbox[(size_t)c * nwords + ((uint64_t)z * qpl + qx) * p.tq + by];
-                    if (w == kEmptyBox) { inside = false; continue; }
-                    any = true;
-                    inside = inside && (w >> 63);
-                    const uint32_t a0 = (uint32_t)(w & 0xffffu), a1 = (uint32_t)((w >> 16) & 0xffffu);
-                    const uint32_t a2 = (uint32_t)((w >> 32) & 0xffffu), a3 = (uint32_t)((w >> 48) & 0x7fffu);
-                    u0 = a0 < u0 ? a0 : u0; v0 = a1 < v0 ? a1 : v0; u1 = a2 > u1 ? a2 : u1; v1 = a3 > v1 ? a3 : v1;
-                }
-        }
-        kbox[(size_t)c * p.nbrick_pad + b] = !any ? kEmptyBox
-            : ((uint64_t)u0 | ((uint64_t)v0 << 16) | ((uint64_t)u1 << 32) | ((uint64_t)v1 << 48) | (inside ? kBoxAllInside : 0ull));
-    }
-}
-
+// The bricks' boxes are built by k_brick_boxes_bm (below).
 // k_cull (every frame set, in front of the hierarchical carve): lane = brick, every camera's brick box against that
 // camera's block grids (LDS).  No foreground block in some camera's box: no voxel of the brick can survive (exact: the box
 // contains the pixel of every voxel of every word of the brick) -- its 64 words are never looked at.  Every block of every
@@ -1085,29 +1057,39 @@ __global__ __launch_bounds__(kBlock) void k_cull(const CarveParams p)
     }
 }
 
-// ---------------------------------------------------------------- strips
+// ---------------------------------------------------------------- brick pipeline
 // The default carve for ny in {256, 512, 1024} (groups of 4096 consecutive voxels then lie inside one brick column).
-// Culling whole bricks leaves a wave of the group-wise kernels with a handful of live lanes: the hull crosses a
-// 1024-voxel line of y in a few bricks only.  So the work is re-cut into STRIPS: one row quad x 64 y x the 16 layers of
-// a brick row = 64 tile words = 4 bricks along y; lane (l, w) holds the word of layer l, tile column w.  A strip with a
-// live brick has at least a quarter of its lanes busy, an interior one all of them.
+// Culling whole bricks leaves a wave of the group-wise kernels with a handful of live lanes (the hull crosses a line of
+// 1024 voxels along y in a few bricks only), and what is left is latency: a wave walks through entry -> boxes -> table ->
+// mask, one dependent round trip after the other, for a few words.  So the work is re-cut by what it needs, one
+// launch per level, each a flat list of equal pieces, every access contiguous:
 //
-//  k_cull_strips   k_cull plus: zeroes the survivor counts of all groups, and appends, for every brick COLUMN with a live
-//                  brick, all its strips to a list (one atomic add per wave): {strip number, live bits, full bits of its 4
-//                  bricks}.  Strips of columns without any live brick are never touched again -- their groups keep count 0
-//                  and nobody reads their words.
-//  k_carve_strips  one wave per listed strip: word boxes against the block grids for the lanes of live, not-full bricks;
-//                  exact per-voxel test for the undecided words (LUT: table entries; else float64 projection), eight words
-//                  at a time; the four tile words of a layer are turned into four y-major words inside their lane quad
-//                  (DPP broadcasts) and stored, their survivors added to the group's count.  A listed strip without a live
-//                  brick stores zeros: every word of a group that can have survivors is valid afterwards.
-struct StripList {
-    uint32_t *entries;          // strip number | live nibble << 20 | full nibble << 24
-    uint32_t *counters;         // [2], used alternately: the launch that fills one zeroes the other
+//  k_cull_bricks   lane = brick: every camera's brick box against the block grids (k_cull).  Appends the bricks that are
+//                  neither dead nor full to the BRICK LIST and the brick columns with a live brick to the COLUMN LIST
+//                  (one atomic per wave and list), zeroes the survivor counts of all groups.
+//  k_brick_words   one wave per listed brick, lane (q, l) = its tile word of row quad q, layer l.  The word boxes come from
+//                  a brick-major copy (512 contiguous bytes per camera).  Decided words (dead / all alive) are stored to the
+//                  brick-major word buffer; undecided ones go to the WORD LIST with the cameras that still have to look.
+//  k_voxel_words   one wave per 8 listed words, lanes = the 64 voxels of a word: table entry (LUT) or float64 projection,
+//                  mask bit, for the listed cameras, two cameras per dependent round trip.  No block grids: no LDS to fill.
+//  k_assemble      one wave per group of the listed columns: collects the group's 64 tile words (dead brick: 0, full
+//                  brick: all ones, else the brick-major buffer), turns them into y-major words (tile_store) and stores
+//                  words + count.  Groups of unlisted columns keep count 0 and nobody reads their words.
+//
+// List lengths stay on the device; the host sizes each launch from the lengths of an EARLIER step (a page-locked
+// word the kernels write, read without any synchronisation), the waves stride over whatever the real length is.
+struct BrickLists {
+    uint32_t *counters;         // [2][4]: bricks, columns, words, -- of this parity; k_cull_bricks zeroes the other set
+    uint32_t *bricks;           // brick numbers (live, not full)
+    uint32_t *columns;          // column numbers (bz * nbx + bx) with a live brick
+    uint64_t *words;            // undecided words: tile word T | need mask (by camera NUMBER) << 32 | slot in bm (brick * 64 + lane) -> second u64
+    uint64_t *bm;               // [nbrick_pad * 64] brick-major tile-word results
+    const uint64_t *wbox;       // [C][nbrick_pad * 64] brick-major word boxes
+    uint32_t *host_counts;      // page-locked [4]
     uint32_t parity;
 };
 
-__global__ __launch_bounds__(kBlock) void k_cull_strips(const CarveParams p, const StripList sl, uint32_t ngroups)
+__global__ __launch_bounds__(kBlock) void k_cull_bricks(const CarveParams p, const BrickLists bl, uint32_t ngroups)
 {
     extern __shared__ uint32_t s_grid[];
     {
@@ -1119,17 +1101,18 @@ __global__ __launch_bounds__(kBlock) void k_cull_strips(const CarveParams p, con
     }
     __shared__ uint32_t s_order[kMaxCameras];
     stage_order(s_grid, p.C, s_order);
-    if (blockIdx.x == 0 && threadIdx.x == 0) sl.counters[sl.parity ^ 1u] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < 4) bl.counters[(bl.parity ^ 1u) * 4 + threadIdx.x] = 0;
+    uint32_t *cnt = bl.counters + bl.parity * 4;
     const uint32_t gshift = hdr_u32(s_grid, kHdrShift);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
     const uint32_t nwaves = gridDim.x * (kBlock / 64);
-    const uint32_t nw = p.nbrick_pad >> 6, qpl = p.nx >> 2;
+    const uint32_t nw = p.nbrick_pad >> 6;
     const uint32_t nbricks = p.nbx * p.tq * p.nbz;
     for (uint32_t i = (blockIdx.x * kBlock + threadIdx.x); i < ngroups; i += gridDim.x * kBlock) p.groupcnt[i] = 0;
     for (uint32_t w = wave0; w < nw; w += nwaves) {
         const uint32_t b = w * 64 + lane;
-        bool cand = true, full = true;
+        bool cand = b < nbricks, full = true;
         for (uint32_t q0 = 0; q0 < p.C && __ballot(cand) != 0; q0 += 4) {
             uint64_t bb[4];
 #pragma unroll
@@ -1145,42 +1128,64 @@ __global__ __launch_bounds__(kBlock) void k_cull_strips(const CarveParams p, con
             }
         }
         const uint64_t lw = __ballot(cand), fw = __ballot(cand && full);
+        p.live[w] = lw;                                           // (all lanes, same value: one store)
+        p.live[nw + w] = fw;
         if (lw == 0) continue;                                    // (wave-uniform)
-        // lane (j, q): the strip of tile columns 4j .. 4j+3 of this wave's bricks, row quad q of its brick column
-        const uint32_t j = lane >> 2, q = lane & 3u;
-        const uint32_t b0 = w * 64 + 4 * j;
-        const uint32_t col = b0 / p.tq, by0 = b0 - col * p.tq;   // tq divides 64: a column never straddles two waves
-        const uint64_t colbits = p.tq == 64 ? lw : (lw >> ((col * p.tq) & 63u)) & ((1ull << p.tq) - 1ull);
-        const uint32_t bz = col / p.nbx, bx = col - bz * p.nbx;
-        const bool want = b0 < nbricks && colbits != 0 && 4 * bx + q < qpl;
-        const uint32_t entry = ((col * 4 + q) * (p.tq >> 2) + (by0 >> 2)) | ((uint32_t)((lw >> (4 * j)) & 15ull) << 20) |
-                               ((uint32_t)((fw >> (4 * j)) & 15ull) << 24);
-        const uint64_t wm = __ballot(want);
-        uint32_t base = 0;
-        if (lane == 0 && wm) base = atomicAdd(&sl.counters[sl.parity], (uint32_t)__popcll(wm));
-        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        if (want) sl.entries[base + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull))] = entry;
+        // bricks to look into
+        const uint64_t bm = lw & ~fw;
+        if (bm) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&cnt[0], (uint32_t)__popcll(bm));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if ((bm >> lane) & 1ull) bl.bricks[base + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull))] = b;
+        }
+        // columns with a live brick: tq divides 64, so a wave holds 64 / tq whole columns; lane j < 64 / tq speaks for column j
+        const uint32_t ncol = 64u / p.tq;
+        const uint64_t colbits = p.tq == 64 ? lw : (lw >> ((lane < ncol ? lane : 0u) * p.tq)) & ((1ull << p.tq) - 1ull);
+        const bool cwant = lane < ncol && colbits != 0;
+        const uint64_t cm = __ballot(cwant);
+        uint32_t cbase = 0;
+        if (lane == 0) cbase = atomicAdd(&cnt[1], (uint32_t)__popcll(cm));
+        cbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)cbase);
+        if (cwant) bl.columns[cbase + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull))] = (w * 64) / p.tq + lane;
     }
 }
 
-__device__ __forceinline__ uint64_t quad_bcast64(uint64_t v, int q)       // value of lane q of this lane's quad
+// Once per grid / slab / camera set: the tile words' pixel boxes in brick-major order (brick b, lane (q, l): row quad
+// 4 bx + q, layer 16 bz + l, tile column by), and from them the bricks' boxes (union; "every voxel inside the image"
+// only if every word has it).  One wave per brick.
+__global__ __launch_bounds__(kBlock) void k_brick_boxes_bm(const CarveParams p, const uint64_t *__restrict__ tbox,
+                                                           uint64_t *__restrict__ wbox, uint64_t *__restrict__ kbox)
 {
-    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-    switch (q) {
-    case 0: lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)lo, 0x00, 0xf, 0xf, true); hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)hi, 0x00, 0xf, 0xf, true); break;
-    case 1: lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)lo, 0x55, 0xf, 0xf, true); hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)hi, 0x55, 0xf, 0xf, true); break;
-    case 2: lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)lo, 0xaa, 0xf, 0xf, true); hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)hi, 0xaa, 0xf, 0xf, true); break;
-    default: lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)lo, 0xff, 0xf, 0xf, true); hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)hi, 0xff, 0xf, 0xf, true); break;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t b = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    if (b >= p.nbrick_pad) return;
+    const uint32_t qpl = p.nx >> 2, nzl = (uint32_t)(p.n / ((uint64_t)p.nx * p.ny));
+    const uint32_t col = b / p.tq, by = b - col * p.tq, bz = col / p.nbx, bx = col - bz * p.nbx;
+    const uint32_t qx = 4 * bx + (lane >> 4), izl = 16 * bz + (lane & 15u);
+    const bool valid = bz < p.nbz && qx < qpl && izl < nzl;
+    const uint64_t nwords = p.n_pad >> 6;
+    for (uint32_t c = 0; c < p.C; ++c) {
+        const uint64_t w = valid ? tbox[(size_t)c * nwords + ((uint64_t)izl * qpl + qx) * p.tq + by] : kEmptyBox;
+        wbox[((size_t)c * p.nbrick_pad + b) * 64 + lane] = w;
+        const bool some = w != kEmptyBox;
+        const uint32_t u0 = wave_min_u32(some ? (uint32_t)(w & 0xffffu) : 0xffffu), v0 = wave_min_u32(some ? (uint32_t)((w >> 16) & 0xffffu) : 0xffffu);
+        const uint32_t u1 = wave_max_u32(some ? (uint32_t)((w >> 32) & 0xffffu) : 0u), v1 = wave_max_u32(some ? (uint32_t)((w >> 48) & 0x7fffu) : 0u);
+        // a word that does not exist (grid edge) does not spoil "inside"; one whose voxels all miss the image does
+        const bool inside = __ballot(valid && !(some && (w >> 63))) == 0;
+        const bool none = __ballot(some) == 0;
+        if (lane == 0)
+            kbox[(size_t)c * p.nbrick_pad + b] = none ? kEmptyBox
+                : ((uint64_t)u0 | ((uint64_t)v0 << 16) | ((uint64_t)u1 << 32) | ((uint64_t)v1 << 48) | (inside ? kBoxAllInside : 0ull));
     }
-    return ((uint64_t)hi << 32) | lo;
 }
 
-template <bool LUT>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_carve_strips(const CarveParams p, const StripList sl)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_brick_words(const CarveParams p, const BrickLists bl)
 {
-    constexpr int B = 8;
     extern __shared__ uint32_t s_grid[];
-    if (blockIdx.x * (kBlock / 64) >= hdr_u32(sl.counters, sl.parity)) return;      // fewer strips than waves launched
+    const uint32_t nlist = hdr_u32(bl.counters, bl.parity * 4);
+    if (blockIdx.x == 0 && threadIdx.x == 0) bl.host_counts[0] = nlist;
+    if (blockIdx.x * (kBlock / 64) >= nlist) return;              // fewer bricks than waves launched
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(p.blockgrid);
         uint4 *dst = reinterpret_cast<uint4 *>(s_grid);
@@ -1194,130 +1199,164 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
     const uint32_t nwaves = gridDim.x * (kBlock / 64);
-    const uint32_t nlist = hdr_u32(sl.counters, sl.parity);
     const uint32_t qpl = p.nx >> 2, nzl = (uint32_t)(p.n / ((uint64_t)p.nx * p.ny));
-    const uint32_t cps = p.tq >> 2, lcps = (uint32_t)__builtin_ctz(cps);     // strips per row quad: a power of two (tq divides 64)
-    const uint64_t nwords = p.n_pad >> 6;
-    const uint32_t l = lane >> 2, w = lane & 3u;
+    uint32_t *cnt = bl.counters + bl.parity * 4;
     for (uint32_t t = wave0; t < nlist; t += nwaves) {
-        const uint32_t e = hdr_u32(sl.entries, t);
-        const uint32_t sn = e & 0xfffffu, nib = (e >> 20) & 15u, fnib = (e >> 24) & 15u;
-        const uint32_t k = sn & (cps - 1u), cq = sn >> lcps, q = cq & 3u, col = cq >> 2;
-        const uint32_t bz = col / p.nbx, bx = col - bz * p.nbx, qx = 4 * bx + q;                 // all wave-uniform
-        const uint32_t izl = 16 * bz + l;
-        const bool valid = izl < nzl;
-        const uint64_t T = ((uint64_t)(valid ? izl : 0u) * qpl + qx) * p.tq + 4 * k + w;      // my tile word
-        bool cand = valid && ((nib >> w) & 1u);
-        const bool full = (fnib >> w) & 1u;
-        uint32_t need = 0;
-        // ---- word level: four cameras' boxes in flight (words of a "full" brick need no look at all)
-        for (uint32_t q0 = 0; q0 < p.C && __ballot(cand && !full) != 0; q0 += 4) {
+        const uint32_t b = hdr_u32(bl.bricks, t);
+        const uint32_t col = b / p.tq, by = b - col * p.tq, bz = col / p.nbx, bx = col - bz * p.nbx;     // wave-uniform
+        const uint32_t qx = 4 * bx + (lane >> 4), izl = 16 * bz + (lane & 15u);
+        bool cand = qx < qpl && izl < nzl;
+        uint32_t need = 0;                                        // by camera NUMBER (k_voxel_words has no use for the order)
+        const size_t slot = (size_t)b * 64 + lane;
+        for (uint32_t q0 = 0; q0 < p.C && __ballot(cand) != 0; q0 += 4) {
             uint64_t bb[4];
+            uint32_t cn[4];
 #pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4)
-                bb[c4] = (q0 + c4 < p.C && cand && !full) ? p.tbox[(size_t)ord(s_order, q0 + c4) * nwords + T] : 0ull;
+            for (int k = 0; k < 4; ++k) {
+                cn[k] = q0 + k < p.C ? ord(s_order, q0 + k) : 0u;
+                bb[k] = (q0 + k < p.C && cand) ? bl.wbox[(size_t)cn[k] * p.nbrick_pad * 64 + slot] : 0ull;
+            }
 #pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4) {
-                if (q0 + c4 < p.C && cand && !full) {
-                    const uint32_t r = box_test(s_grid, load_gridcam(s_grid, ord(s_order, q0 + c4)), bb[c4], gshift);
+            for (int k = 0; k < 4; ++k) {
+                if (q0 + k < p.C && cand) {
+                    const uint32_t r = box_test(s_grid, load_gridcam(s_grid, cn[k]), bb[k], gshift);
                     cand = r != 0;
-                    if (r == 1) need |= 1u << (q0 + c4);
+                    if (r == 1) need |= 1u << cn[k];
                 }
             }
         }
-        uint64_t mine = cand ? ~0ull : 0ull;
         if (!cand) need = 0;
-        // ---- voxel level, lanes = the 64 voxels of an undecided tile word (4 x-rows x 16 y)
-        const uint32_t Tlo = (uint32_t)T, Thi = (uint32_t)(T >> 32);
-        uint64_t nz = __ballot(mine != 0 && need != 0);
+        if (need == 0 || (p.dbg & 1u)) bl.bm[slot] = cand ? ~0ull : 0ull;         // decided here
+        const uint64_t um = (p.dbg & 1u) ? 0ull : __ballot(need != 0);
+        if (um) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&cnt[2], (uint32_t)__popcll(um));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (need) {
+                const uint64_t T = ((uint64_t)izl * qpl + qx) * p.tq + by;
+                const size_t o = 2 * (size_t)(base + (uint32_t)__popcll(um & ((1ull << lane) - 1ull)));
+                bl.words[o] = T | ((uint64_t)need << 32);
+                bl.words[o + 1] = (uint64_t)slot;
+            }
+        }
+    }
+}
+
+// B undecided words per wave (list entries B t .. B t + B - 1), lanes = the 64 voxels of a tile word (4 x-rows x 16 y).
+template <bool LUT>
+__global__ __launch_bounds__(kBlock) void k_voxel_words(const CarveParams p, const BrickLists bl)
+{
+    constexpr int B = 8;
+    const uint32_t nlist = hdr_u32(bl.counters, bl.parity * 4 + 2);
+    if (blockIdx.x == 0 && threadIdx.x == 0) bl.host_counts[2] = nlist;
+    const uint32_t nbatch = (nlist + B - 1) / B;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
+    const uint32_t nwaves = gridDim.x * (kBlock / 64);
+    const uint32_t qpl = p.nx >> 2;
+    for (uint32_t t = wave0; t < nbatch; t += nwaves) {
+        // lane b < B fetches entry b of the batch; everybody gets them by cross-lane reads
+        uint64_t e0 = 0, e1 = 0;
+        if (lane < (uint32_t)B && t * B + lane < nlist) { e0 = bl.words[2 * (size_t)(t * B + lane)]; e1 = bl.words[2 * (size_t)(t * B + lane) + 1]; }
+        uint32_t nd[B], Tb[B];
+        uint32_t alive = 0, ndany = 0;
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            Tb[b] = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)e0, b);
+            nd[b] = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(e0 >> 32), b);
+            if (nd[b]) alive |= 1u << b;
+            ndany |= nd[b];
+        }
         if (LUT) {
-            while (nz != 0) {                                     // wave-uniform; B words at a time so that the dependent loads overlap
-                uint32_t li[B], nd[B];
-                uint64_t Tb[B];
-                uint32_t alive = 0;
+            // cameras in pairs (two tables' entries and mask words per dependent round trip), skipping cameras no word of the batch needs
+            uint32_t left = ndany;
+            while (left) {
+                const uint32_t c = (uint32_t)__builtin_ctz(left);
+                left &= left - 1;
+                uint32_t c2 = c;
+                if (left) { c2 = (uint32_t)__builtin_ctz(left); left &= left - 1; }
+                const int32_t *__restrict__ L1 = p.lut_tile + (size_t)c * p.n_pad + lane;
+                const int32_t *__restrict__ L2 = p.lut_tile + (size_t)c2 * p.n_pad + lane;
+                const uint32_t *__restrict__ mb = p.maskbits + (size_t)c * p.mwords;
+                const uint32_t *__restrict__ mb2 = p.maskbits + (size_t)c2 * p.mwords;
+                int32_t off[B], off2[B];
+                uint32_t mw[B], mw2[B];
 #pragma unroll
-                for (int b = 0; b < B; ++b) {
-                    li[b] = 64; nd[b] = 0; Tb[b] = 0;
-                    if (nz != 0) {
-                        li[b] = (uint32_t)__builtin_ctzll(nz);
-                        nz &= nz - 1;
-                        nd[b] = (uint32_t)__builtin_amdgcn_readlane((int)need, (int)li[b]);
-                        Tb[b] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)Thi, (int)li[b]) << 32) |
-                                (uint32_t)__builtin_amdgcn_readlane((int)Tlo, (int)li[b]);
-                        alive |= 1u << b;
-                    }
-                }
-                uint32_t ndany = 0;
-#pragma unroll
-                for (int b = 0; b < B; ++b) ndany |= nd[b];
-                for (uint32_t qq = 0; qq < p.C; qq += 2) {        // two cameras' entries per dependent round trip
-                    if (((ndany >> qq) & 3u) == 0) continue;
-                    const bool two = qq + 1 < p.C;
-                    const uint32_t c = ord(s_order, qq), c2 = ord(s_order, two ? qq + 1 : qq);
-                    const int32_t *__restrict__ L1 = p.lut_tile + (size_t)c * p.n_pad + lane;
-                    const int32_t *__restrict__ L2 = p.lut_tile + (size_t)c2 * p.n_pad + lane;
-                    const uint32_t *__restrict__ mb = p.maskbits + (size_t)c * p.mwords;
-                    const uint32_t *__restrict__ mb2 = p.maskbits + (size_t)c2 * p.mwords;
-                    int32_t off[B], off2[B];
-                    uint32_t mw[B], mw2[B];
-#pragma unroll
-                    for (int b = 0; b < B; ++b) {                 // a camera outside the word's mask counts as passed
-                        const bool t1 = ((nd[b] >> qq) & 1u) && ((alive >> b) & 1u);
-                        const bool t2 = two && ((nd[b] >> (qq + 1)) & 1u) && ((alive >> b) & 1u);
-                        off[b] = t1 ? L1[Tb[b] * 64] : -2;
-                        off2[b] = t2 ? L2[Tb[b] * 64] : -2;
-                    }
-#pragma unroll
-                    for (int b = 0; b < B; ++b) {
-                        mw[b] = (off[b] >= 0) ? mb[(uint32_t)off[b] >> 5] : (off[b] == -2 ? ~0u : 0u);
-                        mw2[b] = (off2[b] >= 0) ? mb2[(uint32_t)off2[b] >> 5] : (off2[b] == -2 ? ~0u : 0u);
-                    }
-#pragma unroll
-                    for (int b = 0; b < B; ++b)
-                        if (!((mw[b] >> ((uint32_t)off[b] & 31u)) & (mw2[b] >> ((uint32_t)off2[b] & 31u)) & 1u)) alive &= ~(1u << b);
-                    if (__ballot(alive != 0) == 0) break;
+                for (int b = 0; b < B; ++b) {                     // a camera outside the word's mask counts as passed
+                    const bool t1 = ((nd[b] >> c) & 1u) && ((alive >> b) & 1u);
+                    const bool t2 = c2 != c && ((nd[b] >> c2) & 1u) && ((alive >> b) & 1u);
+                    off[b] = t1 ? L1[(size_t)Tb[b] * 64] : -2;
+                    off2[b] = t2 ? L2[(size_t)Tb[b] * 64] : -2;
                 }
 #pragma unroll
                 for (int b = 0; b < B; ++b) {
-                    if (li[b] < 64) {
-                        const uint64_t nb = __ballot((alive >> b) & 1u);
-                        if (lane == li[b]) mine = nb;
-                    }
+                    mw[b] = (off[b] >= 0) ? mb[(uint32_t)off[b] >> 5] : (off[b] == -2 ? ~0u : 0u);
+                    mw2[b] = (off2[b] >= 0) ? mb2[(uint32_t)off2[b] >> 5] : (off2[b] == -2 ? ~0u : 0u);
                 }
+#pragma unroll
+                for (int b = 0; b < B; ++b)
+                    if (!((mw[b] >> ((uint32_t)off[b] & 31u)) & (mw2[b] >> ((uint32_t)off2[b] & 31u)) & 1u)) alive &= ~(1u << b);
+                if (__ballot(alive != 0) == 0) break;
             }
         } else {
-            while (nz != 0) {                                     // table-free: exact float64 projection, one word at a time
-                const uint32_t wl = (uint32_t)__builtin_ctzll(nz);
-                nz &= nz - 1;
-                const uint32_t nd = (uint32_t)__builtin_amdgcn_readlane((int)need, (int)wl);
-                const uint32_t wzl = 16 * bz + (wl >> 2), wty = 4 * k + (wl & 3u);               // that lane's layer and tile column
-                const double VX = p.xs[4 * qx + (lane >> 4)], VY = p.ys[16 * wty + (lane & 15u)], VZ = p.zs[p.z0 + wzl];
-                bool alive = true;
-                for (uint32_t qq = 0; qq < p.C; ++qq) {
-                    if (!((nd >> qq) & 1u)) continue;             // decided for the whole word by its box
-                    const uint32_t c = ord(s_order, qq);
-                    if (alive) {
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                if (nd[b] == 0) continue;
+                const uint32_t quad = Tb[b] / p.tq, ty = Tb[b] - quad * p.tq, zl = quad / qpl, qx = quad - zl * qpl;   // wave-uniform
+                const double VX = p.xs[4 * qx + (lane >> 4)], VY = p.ys[16 * ty + (lane & 15u)], VZ = p.zs[p.z0 + zl];
+                bool ok = true;
+                for (uint32_t left = nd[b]; left; left &= left - 1) {
+                    const uint32_t c = (uint32_t)__builtin_ctz(left);
+                    if (ok) {
                         double u, v;
                         project_point(p.cam[c], VX, VY, VZ, u, v);
                         const int32_t off = pixel_offset(u, v, p.H, p.W);
-                        alive = off >= 0 && mask_bit(p.maskbits + (size_t)c * p.mwords, off);
+                        ok = off >= 0 && mask_bit(p.maskbits + (size_t)c * p.mwords, off);
                     }
-                    if (__ballot(alive) == 0) break;
+                    if (__ballot(ok) == 0) break;
                 }
-                const uint64_t nb = __ballot(alive);
-                if (lane == wl) mine = nb;
+                if (!ok) alive &= ~(1u << b);
             }
         }
-        // ---- the four tile words of a layer -> the four y-major words (rows) of that layer's 64 y, inside the lane quad
-        uint64_t out = 0;
+        uint64_t mine = 0;
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) out |= ((quad_bcast64(mine, qd) >> (16 * w)) & 0xffffull) << (16 * qd);
-        if (valid) {
-            const uint64_t lw = ((uint64_t)izl * p.nx + 4 * qx + w) * (p.ny >> 6) + k;          // lane (l, w) now holds row w
-            p.words[lw] = out;
-            const uint32_t pc = (uint32_t)__popcll(out);
-            if (pc) atomicAdd(&p.groupcnt[lw >> 6], pc);
+        for (int b = 0; b < B; ++b) {
+            const uint64_t nb = __ballot((alive >> b) & 1u);
+            if (lane == (uint32_t)b) mine = nb;
         }
+        if (lane < (uint32_t)B && t * B + lane < nlist) bl.bm[e1] = mine;
+    }
+}
+
+// One wave per group (4096 consecutive voxels = 64 tile words gw .. gw + 63) of the listed brick columns.
+__global__ __launch_bounds__(kBlock) void k_assemble(const CarveParams p, const BrickLists bl)
+{
+    const uint32_t ncols = hdr_u32(bl.counters, bl.parity * 4 + 1);
+    if (blockIdx.x == 0 && threadIdx.x == 0) bl.host_counts[1] = ncols;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
+    const uint32_t nwaves = gridDim.x * (kBlock / 64);
+    const uint32_t qpl = p.nx >> 2, nzl = (uint32_t)(p.n / ((uint64_t)p.nx * p.ny));
+    const uint32_t qpg = 64u / p.tq;                              // row quads per group (1, 2 or 4)
+    const uint32_t gq = 4u / qpg;                                 // groups along x inside a brick column
+    const uint32_t per_col = gq * 16u;
+    const uint32_t nunits = ncols * per_col;
+    const uint32_t nw = p.nbrick_pad >> 6;
+    for (uint32_t u = wave0; u < nunits; u += nwaves) {
+        const uint32_t ci = u / per_col, r = u - ci * per_col, l = r / gq, xg = r - l * gq;     // wave-uniform
+        const uint32_t col = hdr_u32(bl.columns, ci);
+        const uint32_t bz = col / p.nbx, bx = col - bz * p.nbx;
+        const uint32_t izl = 16 * bz + l, qx0 = 4 * bx + xg * qpg;                                 // first row quad of the group
+        if (izl >= nzl || qx0 >= qpl) continue;
+        // lane: tile word (quad qx0 + lane / tq, column lane % tq)
+        const uint32_t dq = lane / p.tq, ty = lane - dq * p.tq, qx = qx0 + dq;
+        const uint32_t b = col * p.tq + ty;
+        const uint64_t lw = p.live[b >> 6], fw = p.live[nw + (b >> 6)];
+        uint64_t mine = 0;
+        if (qx < qpl && ((lw >> (b & 63u)) & 1ull))
+            mine = ((fw >> (b & 63u)) & 1ull) ? ~0ull : bl.bm[(size_t)b * 64 + ((qx & 3u) << 4) + l];
+        const uint64_t gw = ((uint64_t)izl * qpl + qx0) * p.tq;   // first tile word of the group = 64 x its group number
+        tile_store(p, (uint32_t)(gw >> 6), gw, lane, mine);
     }
 }
 

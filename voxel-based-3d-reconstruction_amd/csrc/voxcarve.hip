@@ -193,10 +193,15 @@ struct vc_ctx {
     DevBuf<uint64_t> d_tbox;         // pixel boxes of the tile words
     DevBuf<uint64_t> d_kbox;         // pixel boxes of the 16^3 bricks (64 tile words each)
     DevBuf<uint64_t> d_live;         // per frame set: bit per brick "may hold survivors" | "all voxels survive" (k_cull)
-    DevBuf<uint32_t> d_strips;       // per frame set: the strips of the brick columns with a live brick (k_cull_strips) + 2 counters
-    uint32_t strip_parity = 0;
-    int strips = 1;                  // carve by strips where the grid shape allows (ny in {256, 512, 1024})
-    int strip_blocks_per_cu = 8;
+    // brick pipeline (k_cull_bricks -> k_brick_words -> k_voxel_words -> k_assemble)
+    DevBuf<uint64_t> d_wbox;         // [C][nbrick_pad * 64] brick-major word boxes (geometry only)
+    DevBuf<uint64_t> d_bm;           // [nbrick_pad * 64] brick-major tile-word results of the current step
+    DevBuf<uint32_t> d_blist;        // counters [8] | brick list [nbrick_pad] | column list
+    DevBuf<uint64_t> d_wlist;        // undecided words, two u64 each (worst case: every word of the slab)
+    uint32_t *h_lists = nullptr;     // pinned [4]: list lengths of an earlier step, to size launches by
+    uint32_t list_parity = 0;
+    int strips = 1;                  // carve by bricks where the grid shape allows (ny in {256, 512, 1024}); (option name kept)
+    int dbg = 0;
     bool kbox_valid = false;
     int cull = 1;                    // hierarchical kernels on tile words: cull whole bricks first
     bool tile_valid = false;
@@ -330,27 +335,11 @@ void fill_params(const vc_ctx *ctx, CarveParams &p)
     p.lut_tile = ctx->d_lut_tile.ptr; p.tbox = ctx->d_tbox.ptr; p.tq = ctx->ny / 16;
     p.tile_whole = (p.tq != 0 && 64 % p.tq == 0) ? 1u : 0u;
     p.kbox = ctx->d_kbox.ptr;
+    p.dbg = (uint32_t)ctx->dbg;
     p.live = nullptr;                                            // set by the launches that cull
     p.nbx = ((ctx->nx >> 2) + 3) / 4;
     p.nbz = (ctx->z1 - ctx->z0 + 15) / 16;
     p.nbrick_pad = (uint32_t)(((uint64_t)p.nbx * p.tq * p.nbz + 63) / 64 * 64);
-}
-
-// The bricks' pixel boxes from the tile words' (once per grid / slab / camera set, right behind the tile boxes).
-int build_brick_boxes(vc_ctx *ctx)
-{
-    CarveParams p;
-    fill_params(ctx, p);
-    ctx->kbox_valid = false;
-    if (p.nbrick_pad == 0) return VC_OK;
-    VC_TRY(ensure(ctx, ctx->d_kbox, (size_t)p.nbrick_pad * ctx->C));
-    VC_TRY(ensure(ctx, ctx->d_live, (size_t)(p.nbrick_pad / 64) * 2));
-    p.kbox = ctx->d_kbox.ptr;
-    hipLaunchKernelGGL(k_brick_boxes, dim3(grid_for(p.nbrick_pad)), dim3(kBlock), 0, ctx->stream, p, (const uint64_t *)ctx->d_tbox.ptr,
-                       ctx->d_kbox.ptr);
-    VC_HIP(ctx, hipGetLastError());
-    ctx->kbox_valid = true;
-    return VC_OK;
 }
 
 constexpr int VC_MAX_RANKS = 64;
@@ -361,32 +350,82 @@ constexpr size_t kLdsBytes = 160 * 1024;   // LDS per CU on gfx950
 constexpr size_t kMaxFirstLds = 64 * 1024; // static limit of one workgroup's dynamic LDS without opt-in
 constexpr uint32_t kEstimateSamples = 1u << 16;
 
-// Grid shapes the strip kernels take: a group of 4096 consecutive voxels must lie inside one brick column (see k_carve_strips).
+// The bricks' pixel boxes and the brick-major copy of the word boxes (once per grid / slab / camera set, right behind the
+// tile boxes).
+int build_brick_boxes(vc_ctx *ctx)
+{
+    CarveParams p;
+    fill_params(ctx, p);
+    ctx->kbox_valid = false;
+    if (p.nbrick_pad == 0) return VC_OK;
+    VC_TRY(ensure(ctx, ctx->d_kbox, (size_t)p.nbrick_pad * ctx->C));
+    VC_TRY(ensure(ctx, ctx->d_live, (size_t)(p.nbrick_pad / 64) * 2));
+    VC_TRY(ensure(ctx, ctx->d_wbox, (size_t)p.nbrick_pad * 64 * ctx->C));
+    p.kbox = ctx->d_kbox.ptr;
+    hipLaunchKernelGGL(k_brick_boxes_bm, dim3(p.nbrick_pad / 4), dim3(kBlock), 0, ctx->stream, p, (const uint64_t *)ctx->d_tbox.ptr,
+                       ctx->d_wbox.ptr, ctx->d_kbox.ptr);
+    VC_HIP(ctx, hipGetLastError());
+    ctx->kbox_valid = true;
+    if (ctx->h_lists) ctx->h_lists[0] = ctx->h_lists[1] = ctx->h_lists[2] = 0xffffffffu;
+    return VC_OK;
+}
+
+// Grid shapes the brick pipeline takes: a group of 4096 consecutive voxels must lie inside one brick column (see k_assemble).
 bool strip_shape(const vc_ctx *ctx, const CarveParams &p)
 {
     if (!ctx->strips || !ctx->cull || !ctx->kbox_valid) return false;
     if (ctx->ny != 256 && ctx->ny != 512 && ctx->ny != 1024) return false;
     if (ctx->nx % (4096u / ctx->ny) != 0 || ctx->nx % 4 != 0) return false;
-    return (uint64_t)p.nbx * p.tq * p.nbz <= (1u << 20);
+    return true;
+}
+
+uint32_t sized(uint32_t known, uint64_t unknown_guess, uint64_t cap, uint32_t per_wg)
+{
+    uint64_t est = known == 0xffffffffu ? unknown_guess : (uint64_t)known + known / 4 + 64;
+    if (est > cap) est = cap;
+    uint64_t wgs = (est + per_wg - 1) / per_wg;
+    if (wgs < 64) wgs = 64;
+    if (wgs > 65536) wgs = 65536;
+    return (uint32_t)wgs;
 }
 
 template <bool LUT>
-int launch_strips(vc_ctx *ctx, CarveParams &p, size_t lds, uint32_t ngroups)
+int launch_bricks(vc_ctx *ctx, CarveParams &p, size_t lds, uint32_t ngroups)
 {
-    const size_t need = (size_t)p.nbrick_pad + 64 + 2;
-    if (ctx->d_strips.cap < need) {
-        VC_TRY(ensure(ctx, ctx->d_strips, need));
-        VC_HIP(ctx, hipMemsetAsync(ctx->d_strips.ptr, 0, 2 * sizeof(uint32_t), ctx->stream));      // both counters
-        ctx->strip_parity = 0;
+    const uint32_t ncolumns = p.nbx * p.nbz;
+    VC_TRY(ensure(ctx, ctx->d_bm, (size_t)p.nbrick_pad * 64));
+    VC_TRY(ensure(ctx, ctx->d_wlist, (size_t)p.nbrick_pad * 64 * 2));
+    const size_t need = 8 + (size_t)p.nbrick_pad + ncolumns + 64;
+    if (ctx->d_blist.cap < need) {
+        VC_TRY(ensure(ctx, ctx->d_blist, need));
+        VC_HIP(ctx, hipMemsetAsync(ctx->d_blist.ptr, 0, 8 * sizeof(uint32_t), ctx->stream));        // both sets of list lengths
+        ctx->list_parity = 0;
     }
-    StripList sl;
-    sl.counters = ctx->d_strips.ptr;
-    sl.entries = ctx->d_strips.ptr + 2;
-    sl.parity = (ctx->strip_parity ^= 1u);
+    if (!ctx->h_lists) {
+        VC_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_lists), 4 * sizeof(uint32_t), hipHostMallocDefault));
+        ctx->h_lists[0] = ctx->h_lists[1] = ctx->h_lists[2] = ctx->h_lists[3] = 0xffffffffu;       // unknown yet
+    }
+    BrickLists bl;
+    bl.counters = ctx->d_blist.ptr;
+    bl.bricks = ctx->d_blist.ptr + 8;
+    bl.columns = bl.bricks + p.nbrick_pad;
+    bl.words = ctx->d_wlist.ptr;
+    bl.bm = ctx->d_bm.ptr;
+    bl.wbox = ctx->d_wbox.ptr;
+    bl.host_counts = ctx->h_lists;
+    bl.parity = (ctx->list_parity ^= 1u);
     p.live = ctx->d_live.ptr;
+    const volatile uint32_t *known = ctx->h_lists;                // lengths of an earlier step (any size is correct: the waves stride)
+    const uint32_t k_bricks = known[0], k_cols = known[1], k_words = known[2];
     const uint32_t cw = p.nbrick_pad / 256;
-    hipLaunchKernelGGL(k_cull_strips, dim3(cw < 1 ? 1 : (cw > 1024 ? 1024 : cw)), dim3(kBlock), lds, ctx->stream, p, sl, ngroups);
-    hipLaunchKernelGGL((k_carve_strips<LUT>), dim3(256u * (uint32_t)ctx->strip_blocks_per_cu), dim3(kBlock), lds, ctx->stream, p, sl);
+    const dim3 block(kBlock);
+    hipLaunchKernelGGL(k_cull_bricks, dim3(cw < 1 ? 1 : (cw > 1024 ? 1024 : cw)), block, lds, ctx->stream, p, bl, ngroups);
+    hipLaunchKernelGGL(k_brick_words, dim3(sized(k_bricks, p.nbrick_pad / 8, p.nbrick_pad, 4)), block, lds, ctx->stream, p, bl);
+    hipLaunchKernelGGL((k_voxel_words<LUT>), dim3(sized(k_words, (uint64_t)p.nbrick_pad * 4, (uint64_t)p.nbrick_pad * 64, 32)), block, 0,
+                       ctx->stream, p, bl);
+    const uint32_t per_col = (4u / (64u / p.tq)) * 16u;
+    hipLaunchKernelGGL(k_assemble, dim3(sized(k_cols == 0xffffffffu ? k_cols : k_cols * per_col, (uint64_t)ncolumns * per_col / 4,
+                                              (uint64_t)ncolumns * per_col, 4)), block, 0, ctx->stream, p, bl);
     VC_HIP(ctx, hipGetLastError());
     return VC_OK;
 }
@@ -786,7 +825,7 @@ int vc_destroy(vc_ctx *ctx)
         if (s.e_up) (void)hipEventDestroy(s.e_up);
     }
     for (int k = 0; k < 2; ++k) if (ctx->ev_h[k]) (void)hipEventDestroy(ctx->ev_h[k]);
-    release(ctx->d_axes); release(ctx->d_morph); release(ctx->d_lut); release(ctx->d_bbox); release(ctx->d_lut_tile); release(ctx->d_tbox); release(ctx->d_kbox); release(ctx->d_live); release(ctx->d_strips);
+    release(ctx->d_axes); release(ctx->d_morph); release(ctx->d_lut); release(ctx->d_bbox); release(ctx->d_lut_tile); release(ctx->d_tbox); release(ctx->d_kbox); release(ctx->d_live); release(ctx->d_wbox); release(ctx->d_bm); release(ctx->d_blist); release(ctx->d_wlist);
     for (StepBuf &b : ctx->sb) {
         release(b.words); release(b.groupcnt); release(b.groupoff); release(b.blocksum); release(b.blockoff); release(b.records);
         release(b.ent); release(b.mine); release(b.counts);
@@ -805,6 +844,7 @@ int vc_destroy(vc_ctx *ctx)
     release(ctx->d_xboff); release(ctx->d_lut_color);
     release(ctx->d_ycnt); release(ctx->d_yoff); release(ctx->d_ybsum); release(ctx->d_yboff);
     if (ctx->h_xtotal) (void)hipHostFree(ctx->h_xtotal);
+    if (ctx->h_lists) (void)hipHostFree(ctx->h_lists);
     if (ctx->h_total) (void)hipHostFree(ctx->h_total);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
     for (int i = 0; i < 4; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
@@ -847,6 +887,7 @@ int vc_set_grid(vc_ctx *ctx, uint32_t nx, uint32_t ny, uint32_t nz, const double
     VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->have_grid = true;
     for (Slot &sl : ctx->slots) sl.grids_valid = false;       // the camera order was sampled on the old geometry
+    if (ctx->h_lists) ctx->h_lists[0] = ctx->h_lists[1] = ctx->h_lists[2] = 0xffffffffu;
     ctx->lut_valid = false; ctx->bbox_valid = false; ctx->tbox_valid = false; ctx->kbox_valid = false; ctx->carved = false; ctx->gathered = false; ctx->viewmask_valid = false;
     ctx->lut_color_cam = -1; ctx->packed = false;
     return VC_OK;
@@ -1168,8 +1209,8 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
                     sb.sparse_words = false;
                 }
                 if (strip_shape(ctx, p)) {
-                    sb.sparse_words = true;              // (k_cull_strips zeroes every group's count itself)
-                    VC_TRY(launch_strips<true>(ctx, p, lds, ngroups));
+                    sb.sparse_words = true;              // (k_cull_bricks zeroes every group's count itself)
+                    VC_TRY(launch_bricks<true>(ctx, p, lds, ngroups));
                 } else {
                     if (ctx->cull && ctx->kbox_valid) {
                         p.live = ctx->d_live.ptr;
@@ -1223,7 +1264,7 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
                     p.kbox = ctx->d_kbox.ptr;
                     if (strip_shape(ctx, p)) {
                         sb.sparse_words = true;
-                        VC_TRY(launch_strips<false>(ctx, p, lds, ngroups));
+                        VC_TRY(launch_bricks<false>(ctx, p, lds, ngroups));
                     } else {
                         if (ctx->cull && ctx->kbox_valid) {
                             p.live = ctx->d_live.ptr;
@@ -1495,7 +1536,7 @@ int vc_set_option(vc_ctx *ctx, const char *name, int value)
     else if (k == "timing_detail") ctx->timing_detail = value != 0;
     else if (k == "cull") ctx->cull = value != 0;
     else if (k == "strips") ctx->strips = value != 0;
-    else if (k == "strip_blocks_per_cu" && value >= 1 && value <= 64) ctx->strip_blocks_per_cu = value;
+    else if (k == "dbg") ctx->dbg = value;
     else if (k == "emit_busy" && value >= 0 && value <= 2) ctx->emit_busy = value;          // 0 never, 1 large grids, 2 always
     else if (k == "emit_waves_per_cu" && value >= 4 && value <= 1024) ctx->emit_waves_per_cu = value;
     else if (k == "lut_tile") ctx->lut_tile = value != 0;
@@ -1515,6 +1556,29 @@ int vc_set_option(vc_ctx *ctx, const char *name, int value)
     else if (k == "refine_blocks_per_cu" && value >= 1 && value <= 64) ctx->refine_blocks_per_cu = value;
     else if (k == "fused_blocks_per_cu" && value >= 1 && value <= 16) ctx->fused_blocks_per_cu = value;
     else return fail(ctx, VC_ERR_ARG, "unknown option or bad value: %s = %d", name, value);
+    return VC_OK;
+}
+
+int vc_debug_counters(vc_ctx *ctx, uint64_t out[8])
+{
+    if (!ctx || !out) return VC_ERR_ARG;
+    VC_HIP(ctx, hipSetDevice(ctx->device));
+    VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memset(out, 0, 8 * sizeof(uint64_t));
+    CarveParams p;
+    fill_params(ctx, p);
+    if (ctx->d_blist.ptr) {
+        uint32_t c[8];
+        VC_HIP(ctx, hipMemcpy(c, ctx->d_blist.ptr, sizeof c, hipMemcpyDeviceToHost));
+        out[0] = c[ctx->list_parity * 4]; out[4] = c[ctx->list_parity * 4 + 1]; out[5] = c[ctx->list_parity * 4 + 2];
+    }
+    if (ctx->d_live.ptr && ctx->kbox_valid) {
+        const size_t nw = p.nbrick_pad / 64;
+        std::vector<uint64_t> bits(2 * nw);
+        VC_HIP(ctx, hipMemcpy(bits.data(), ctx->d_live.ptr, bits.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < nw; ++i) { out[1] += (uint64_t)__builtin_popcountll(bits[i]); out[2] += (uint64_t)__builtin_popcountll(bits[nw + i]); }
+        out[3] = (uint64_t)p.nbx * p.tq * p.nbz;
+    }
     return VC_OK;
 }
 

@@ -230,6 +230,12 @@ class CarveEngine:
         """Launch-geometry tuning knobs (never change results); see vc_set_option."""
         self._check(self._L.vc_set_option(self._ctx, name.encode(), int(value)), "vc_set_option")
 
+    def debug_counters(self):
+        out = np.zeros(8, dtype=np.uint64)
+        self._check(self._L.vc_debug_counters(self._ctx, _ptr(out, ctypes.c_uint64)), "vc_debug_counters")
+        return {"bricks_listed": int(out[0]), "bricks_live": int(out[1]), "bricks_full": int(out[2]), "bricks": int(out[3]),
+                "columns_listed": int(out[4]), "words_undecided": int(out[5])}
+
     def synchronize(self):
         self._check(self._L.vc_synchronize(self._ctx), "vc_synchronize")
 
