@@ -1078,16 +1078,51 @@ __global__ __launch_bounds__(kBlock) void k_cull(const CarveParams p)
 //
 // List lengths stay on the device; the host sizes each launch from the lengths of an EARLIER step (a page-locked
 // word the kernels write, read without any synchronisation), the waves stride over whatever the real length is.
+// The lists are SHARDED: a returning atomic on one address takes ~12 ns, so 6 000 waves reserving their list space from a
+// single counter would serialise for longer than their work.  Shard s (of kShards) has its own counter and its own region
+// [s * cap, (s + 1) * cap) with cap = the most its producers (the waves w with w % kShards == s) can ever append, so no
+// shard can overflow.  A consumer wave scans the kShards counts once (lane = shard) and finds the shard of flat item t by
+// a ballot over the exclusive prefix.
+constexpr uint32_t kShards = 64;
 struct BrickLists {
-    uint32_t *counters;         // [2][4]: bricks, columns, words, -- of this parity; k_cull_bricks zeroes the other set
+    uint32_t *counters;         // [2][3][kShards]: bricks, columns, words, of this parity; k_cull_bricks zeroes the other set
     uint32_t *bricks;           // brick numbers (live, not full)
     uint32_t *columns;          // column numbers (bz * nbx + bx) with a live brick
-    uint64_t *words;            // undecided words: tile word T | need mask (by camera NUMBER) << 32 | slot in bm (brick * 64 + lane) -> second u64
+    uint64_t *words;            // undecided words, two u64 each: tile word T | need mask (by camera NUMBER) << 32, then slot in bm
     uint64_t *bm;               // [nbrick_pad * 64] brick-major tile-word results
     const uint64_t *wbox;       // [C][nbrick_pad * 64] brick-major word boxes
     uint32_t *host_counts;      // page-locked [4]
     uint32_t parity;
+    uint32_t cap_b, cap_c, cap_w;   // shard capacities of the three lists (entries)
 };
+
+// producer: space for popcount(mask) entries in shard `shard`; returns this lane's entry index (valid where its mask bit is set)
+__device__ __forceinline__ uint32_t shard_append(uint32_t *counts, uint32_t cap, uint32_t shard, uint64_t mask, uint32_t lane)
+{
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&counts[shard], (uint32_t)__popcll(mask));
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    return shard * cap + base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+// consumer: lane s gets the exclusive prefix of the shard sizes (in units of `per`, rounded up per shard) and its own size
+struct ShardView { uint32_t start, size, total; };
+__device__ __forceinline__ ShardView shard_view(const uint32_t *counts, uint32_t per, uint32_t lane)
+{
+    ShardView v;
+    v.size = counts[lane];
+    const uint32_t units = (v.size + per - 1) / per;
+    const uint32_t incl = wave_inclusive_scan(units, lane);
+    v.start = incl - units;
+    v.total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    return v;
+}
+// unit t (wave-uniform, < total) -> its shard and its unit number inside the shard
+__device__ __forceinline__ void shard_locate(const ShardView &v, uint32_t t, uint32_t &shard, uint32_t &within, uint32_t &size)
+{
+    shard = (uint32_t)__popcll(__ballot(v.start <= t)) - 1u;
+    within = t - (uint32_t)__builtin_amdgcn_readlane((int)v.start, (int)shard);
+    size = (uint32_t)__builtin_amdgcn_readlane((int)v.size, (int)shard);
+}
 
 __global__ __launch_bounds__(kBlock) void k_cull_bricks(const CarveParams p, const BrickLists bl, uint32_t ngroups)
 {
@@ -1101,8 +1136,8 @@ __global__ __launch_bounds__(kBlock) void k_cull_bricks(const CarveParams p, con
     }
     __shared__ uint32_t s_order[kMaxCameras];
     stage_order(s_grid, p.C, s_order);
-    if (blockIdx.x == 0 && threadIdx.x < 4) bl.counters[(bl.parity ^ 1u) * 4 + threadIdx.x] = 0;
-    uint32_t *cnt = bl.counters + bl.parity * 4;
+    if (blockIdx.x == 0 && threadIdx.x < 3 * kShards) bl.counters[(bl.parity ^ 1u) * 3 * kShards + threadIdx.x] = 0;
+    uint32_t *cnt = bl.counters + bl.parity * 3 * kShards;
     const uint32_t gshift = hdr_u32(s_grid, kHdrShift);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
@@ -1134,20 +1169,16 @@ __global__ __launch_bounds__(kBlock) void k_cull_bricks(const CarveParams p, con
         // bricks to look into
         const uint64_t bm = lw & ~fw;
         if (bm) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&cnt[0], (uint32_t)__popcll(bm));
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            if ((bm >> lane) & 1ull) bl.bricks[base + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull))] = b;
+            const uint32_t at = shard_append(cnt, bl.cap_b, w % kShards, bm, lane);
+            if ((bm >> lane) & 1ull) bl.bricks[at] = b;
         }
         // columns with a live brick: tq divides 64, so a wave holds 64 / tq whole columns; lane j < 64 / tq speaks for column j
         const uint32_t ncol = 64u / p.tq;
         const uint64_t colbits = p.tq == 64 ? lw : (lw >> ((lane < ncol ? lane : 0u) * p.tq)) & ((1ull << p.tq) - 1ull);
         const bool cwant = lane < ncol && colbits != 0;
         const uint64_t cm = __ballot(cwant);
-        uint32_t cbase = 0;
-        if (lane == 0) cbase = atomicAdd(&cnt[1], (uint32_t)__popcll(cm));
-        cbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)cbase);
-        if (cwant) bl.columns[cbase + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull))] = (w * 64) / p.tq + lane;
+        const uint32_t cat = shard_append(cnt + kShards, bl.cap_c, w % kShards, cm, lane);
+        if (cwant) bl.columns[cat] = (w * 64) / p.tq + lane;
     }
 }
 
@@ -1183,7 +1214,9 @@ __global__ __launch_bounds__(kBlock) void k_brick_boxes_bm(const CarveParams p, 
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_brick_words(const CarveParams p, const BrickLists bl)
 {
     extern __shared__ uint32_t s_grid[];
-    const uint32_t nlist = hdr_u32(bl.counters, bl.parity * 4);
+    uint32_t *cnt = bl.counters + bl.parity * 3 * kShards;
+    const ShardView sv = shard_view(cnt, 1, threadIdx.x & 63u);
+    const uint32_t nlist = sv.total;
     if (blockIdx.x == 0 && threadIdx.x == 0) bl.host_counts[0] = nlist;
     if (blockIdx.x * (kBlock / 64) >= nlist) return;              // fewer bricks than waves launched
     {
@@ -1200,9 +1233,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
     const uint32_t nwaves = gridDim.x * (kBlock / 64);
     const uint32_t qpl = p.nx >> 2, nzl = (uint32_t)(p.n / ((uint64_t)p.nx * p.ny));
-    uint32_t *cnt = bl.counters + bl.parity * 4;
     for (uint32_t t = wave0; t < nlist; t += nwaves) {
-        const uint32_t b = hdr_u32(bl.bricks, t);
+        uint32_t shard, within, ssize;
+        shard_locate(sv, t, shard, within, ssize);
+        const uint32_t b = hdr_u32(bl.bricks, shard * bl.cap_b + within);
         const uint32_t col = b / p.tq, by = b - col * p.tq, bz = col / p.nbx, bx = col - bz * p.nbx;     // wave-uniform
         const uint32_t qx = 4 * bx + (lane >> 4), izl = 16 * bz + (lane & 15u);
         bool cand = qx < qpl && izl < nzl;
@@ -1229,12 +1263,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         if (need == 0 || (p.dbg & 1u)) bl.bm[slot] = cand ? ~0ull : 0ull;         // decided here
         const uint64_t um = (p.dbg & 1u) ? 0ull : __ballot(need != 0);
         if (um) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&cnt[2], (uint32_t)__popcll(um));
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            const size_t o = 2 * (size_t)shard_append(cnt + 2 * kShards, bl.cap_w, t % kShards, um, lane);
             if (need) {
                 const uint64_t T = ((uint64_t)izl * qpl + qx) * p.tq + by;
-                const size_t o = 2 * (size_t)(base + (uint32_t)__popcll(um & ((1ull << lane) - 1ull)));
                 bl.words[o] = T | ((uint64_t)need << 32);
                 bl.words[o + 1] = (uint64_t)slot;
             }
@@ -1247,17 +1278,21 @@ template <bool LUT>
 __global__ __launch_bounds__(kBlock) void k_voxel_words(const CarveParams p, const BrickLists bl)
 {
     constexpr int B = 8;
-    const uint32_t nlist = hdr_u32(bl.counters, bl.parity * 4 + 2);
-    if (blockIdx.x == 0 && threadIdx.x == 0) bl.host_counts[2] = nlist;
-    const uint32_t nbatch = (nlist + B - 1) / B;
     const uint32_t lane = threadIdx.x & 63u;
+    const ShardView sv = shard_view(bl.counters + (bl.parity * 3 + 2) * kShards, B, lane);    // in batches of B words, per shard
+    const uint32_t nbatch = sv.total;
+    if (blockIdx.x == 0 && threadIdx.x == 0) bl.host_counts[2] = nbatch * B;
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
     const uint32_t nwaves = gridDim.x * (kBlock / 64);
     const uint32_t qpl = p.nx >> 2;
     for (uint32_t t = wave0; t < nbatch; t += nwaves) {
         // lane b < B fetches entry b of the batch; everybody gets them by cross-lane reads
+        uint32_t shard, within, ssize;
+        shard_locate(sv, t, shard, within, ssize);
+        const bool mine_valid = lane < (uint32_t)B && within * B + lane < ssize;
+        const size_t at = (size_t)shard * bl.cap_w + within * B + lane;
         uint64_t e0 = 0, e1 = 0;
-        if (lane < (uint32_t)B && t * B + lane < nlist) { e0 = bl.words[2 * (size_t)(t * B + lane)]; e1 = bl.words[2 * (size_t)(t * B + lane) + 1]; }
+        if (mine_valid) { e0 = bl.words[2 * at]; e1 = bl.words[2 * at + 1]; }
         uint32_t nd[B], Tb[B];
         uint32_t alive = 0, ndany = 0;
 #pragma unroll
@@ -1324,16 +1359,17 @@ __global__ __launch_bounds__(kBlock) void k_voxel_words(const CarveParams p, con
             const uint64_t nb = __ballot((alive >> b) & 1u);
             if (lane == (uint32_t)b) mine = nb;
         }
-        if (lane < (uint32_t)B && t * B + lane < nlist) bl.bm[e1] = mine;
+        if (mine_valid) bl.bm[e1] = mine;
     }
 }
 
 // One wave per group (4096 consecutive voxels = 64 tile words gw .. gw + 63) of the listed brick columns.
 __global__ __launch_bounds__(kBlock) void k_assemble(const CarveParams p, const BrickLists bl)
 {
-    const uint32_t ncols = hdr_u32(bl.counters, bl.parity * 4 + 1);
-    if (blockIdx.x == 0 && threadIdx.x == 0) bl.host_counts[1] = ncols;
     const uint32_t lane = threadIdx.x & 63u;
+    const ShardView sv = shard_view(bl.counters + (bl.parity * 3 + 1) * kShards, 1, lane);
+    const uint32_t ncols = sv.total;
+    if (blockIdx.x == 0 && threadIdx.x == 0) bl.host_counts[1] = ncols;
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
     const uint32_t nwaves = gridDim.x * (kBlock / 64);
     const uint32_t qpl = p.nx >> 2, nzl = (uint32_t)(p.n / ((uint64_t)p.nx * p.ny));
@@ -1344,7 +1380,9 @@ __global__ __launch_bounds__(kBlock) void k_assemble(const CarveParams p, const 
     const uint32_t nw = p.nbrick_pad >> 6;
     for (uint32_t u = wave0; u < nunits; u += nwaves) {
         const uint32_t ci = u / per_col, r = u - ci * per_col, l = r / gq, xg = r - l * gq;     // wave-uniform
-        const uint32_t col = hdr_u32(bl.columns, ci);
+        uint32_t shard, within, ssize;
+        shard_locate(sv, ci, shard, within, ssize);
+        const uint32_t col = hdr_u32(bl.columns, shard * bl.cap_c + within);
         const uint32_t bz = col / p.nbx, bx = col - bz * p.nbx;
         const uint32_t izl = 16 * bz + l, qx0 = 4 * bx + xg * qpg;                                 // first row quad of the group
         if (izl >= nzl || qx0 >= qpl) continue;

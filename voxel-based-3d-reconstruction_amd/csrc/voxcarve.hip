@@ -393,27 +393,32 @@ template <bool LUT>
 int launch_bricks(vc_ctx *ctx, CarveParams &p, size_t lds, uint32_t ngroups)
 {
     const uint32_t ncolumns = p.nbx * p.nbz;
+    const uint32_t nw = p.nbrick_pad / 64;                                    // waves of k_cull_bricks
+    const uint32_t wps = (nw + kShards - 1) / kShards;                        // producers per shard
+    BrickLists bl;
+    bl.cap_b = wps * 64; bl.cap_c = wps * 4;
+    bl.cap_w = (p.nbrick_pad + kShards - 1) / kShards * 64;                   // a listed brick appends at most its 64 words
     VC_TRY(ensure(ctx, ctx->d_bm, (size_t)p.nbrick_pad * 64));
-    VC_TRY(ensure(ctx, ctx->d_wlist, (size_t)p.nbrick_pad * 64 * 2));
-    const size_t need = 8 + (size_t)p.nbrick_pad + ncolumns + 64;
+    VC_TRY(ensure(ctx, ctx->d_wlist, (size_t)bl.cap_w * kShards * 2));
+    const size_t need = 6 * kShards + (size_t)bl.cap_b * kShards + (size_t)bl.cap_c * kShards + 64;
     if (ctx->d_blist.cap < need) {
         VC_TRY(ensure(ctx, ctx->d_blist, need));
-        VC_HIP(ctx, hipMemsetAsync(ctx->d_blist.ptr, 0, 8 * sizeof(uint32_t), ctx->stream));        // both sets of list lengths
+        VC_HIP(ctx, hipMemsetAsync(ctx->d_blist.ptr, 0, 6 * kShards * sizeof(uint32_t), ctx->stream));   // both sets of list lengths
         ctx->list_parity = 0;
     }
     if (!ctx->h_lists) {
         VC_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_lists), 4 * sizeof(uint32_t), hipHostMallocDefault));
         ctx->h_lists[0] = ctx->h_lists[1] = ctx->h_lists[2] = ctx->h_lists[3] = 0xffffffffu;       // unknown yet
     }
-    BrickLists bl;
     bl.counters = ctx->d_blist.ptr;
-    bl.bricks = ctx->d_blist.ptr + 8;
-    bl.columns = bl.bricks + p.nbrick_pad;
+    bl.bricks = ctx->d_blist.ptr + 6 * kShards;
+    bl.columns = bl.bricks + (size_t)bl.cap_b * kShards;
     bl.words = ctx->d_wlist.ptr;
     bl.bm = ctx->d_bm.ptr;
     bl.wbox = ctx->d_wbox.ptr;
     bl.host_counts = ctx->h_lists;
     bl.parity = (ctx->list_parity ^= 1u);
+    (void)ncolumns;
     p.live = ctx->d_live.ptr;
     const volatile uint32_t *known = ctx->h_lists;                // lengths of an earlier step (any size is correct: the waves stride)
     const uint32_t k_bricks = known[0], k_cols = known[1], k_words = known[2];
@@ -1568,9 +1573,10 @@ int vc_debug_counters(vc_ctx *ctx, uint64_t out[8])
     CarveParams p;
     fill_params(ctx, p);
     if (ctx->d_blist.ptr) {
-        uint32_t c[8];
+        uint32_t c[6 * kShards];
         VC_HIP(ctx, hipMemcpy(c, ctx->d_blist.ptr, sizeof c, hipMemcpyDeviceToHost));
-        out[0] = c[ctx->list_parity * 4]; out[4] = c[ctx->list_parity * 4 + 1]; out[5] = c[ctx->list_parity * 4 + 2];
+        const uint32_t *q = c + ctx->list_parity * 3 * kShards;
+        for (uint32_t k = 0; k < kShards; ++k) { out[0] += q[k]; out[4] += q[kShards + k]; out[5] += q[2 * kShards + k]; }
     }
     if (ctx->d_live.ptr && ctx->kbox_valid) {
         const size_t nw = p.nbrick_pad / 64;
