@@ -1084,23 +1084,25 @@ __global__ __launch_bounds__(kBlock) void k_cull(const CarveParams p)
 // shard can overflow.  A consumer wave scans the kShards counts once (lane = shard) and finds the shard of flat item t by
 // a ballot over the exclusive prefix.
 constexpr uint32_t kShards = 64;
+constexpr uint32_t kShardStride = 32;   // u32 between two shard counters: one 128-byte line each (atomics on one LINE serialise too)
 struct BrickLists {
-    uint32_t *counters;         // [2][3][kShards]: bricks, columns, words, of this parity; k_cull_bricks zeroes the other set
+    uint32_t *counters;         // [2][3][kShards * kShardStride]: bricks, columns, words, of this parity; k_cull_bricks zeroes the other set
     uint32_t *bricks;           // brick numbers (live, not full)
     uint32_t *columns;          // column numbers (bz * nbx + bx) with a live brick
-    uint64_t *words;            // undecided words, two u64 each: tile word T | need mask (by camera NUMBER) << 32, then slot in bm
-    uint64_t *bm;               // [nbrick_pad * 64] brick-major tile-word results
+    uint64_t *words;            // undecided words: tile word T | need mask (by camera NUMBER) << 32
+    uint64_t *bm;               // [n_pad / 64] the tile words' results, tile order (k_assemble reads 512 contiguous bytes per group)
     const uint64_t *wbox;       // [C][nbrick_pad * 64] brick-major word boxes
     uint32_t *host_counts;      // page-locked [4]
     uint32_t parity;
     uint32_t cap_b, cap_c, cap_w;   // shard capacities of the three lists (entries)
+    uint64_t *trace;            // experiments (dbg & 32): per wave of k_brick_words {entry, staged, done} in 10 ns ticks
 };
 
 // producer: space for popcount(mask) entries in shard `shard`; returns this lane's entry index (valid where its mask bit is set)
 __device__ __forceinline__ uint32_t shard_append(uint32_t *counts, uint32_t cap, uint32_t shard, uint64_t mask, uint32_t lane)
 {
     uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&counts[shard], (uint32_t)__popcll(mask));
+    if (lane == 0) base = atomicAdd(&counts[shard * kShardStride], (uint32_t)__popcll(mask));
     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
     return shard * cap + base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
@@ -1109,7 +1111,7 @@ struct ShardView { uint32_t start, size, total; };
 __device__ __forceinline__ ShardView shard_view(const uint32_t *counts, uint32_t per, uint32_t lane)
 {
     ShardView v;
-    v.size = counts[lane];
+    v.size = counts[lane * kShardStride];
     const uint32_t units = (v.size + per - 1) / per;
     const uint32_t incl = wave_inclusive_scan(units, lane);
     v.start = incl - units;
@@ -1136,8 +1138,8 @@ __global__ __launch_bounds__(kBlock) void k_cull_bricks(const CarveParams p, con
     }
     __shared__ uint32_t s_order[kMaxCameras];
     stage_order(s_grid, p.C, s_order);
-    if (blockIdx.x == 0 && threadIdx.x < 3 * kShards) bl.counters[(bl.parity ^ 1u) * 3 * kShards + threadIdx.x] = 0;
-    uint32_t *cnt = bl.counters + bl.parity * 3 * kShards;
+    if (blockIdx.x == 0 && threadIdx.x < 3 * kShards) bl.counters[((bl.parity ^ 1u) * 3 * kShards + threadIdx.x) * kShardStride] = 0;
+    uint32_t *cnt = bl.counters + bl.parity * 3 * kShards * kShardStride;
     const uint32_t gshift = hdr_u32(s_grid, kHdrShift);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
@@ -1177,7 +1179,7 @@ __global__ __launch_bounds__(kBlock) void k_cull_bricks(const CarveParams p, con
         const uint64_t colbits = p.tq == 64 ? lw : (lw >> ((lane < ncol ? lane : 0u) * p.tq)) & ((1ull << p.tq) - 1ull);
         const bool cwant = lane < ncol && colbits != 0;
         const uint64_t cm = __ballot(cwant);
-        const uint32_t cat = shard_append(cnt + kShards, bl.cap_c, w % kShards, cm, lane);
+        const uint32_t cat = shard_append(cnt + kShards * kShardStride, bl.cap_c, w % kShards, cm, lane);
         if (cwant) bl.columns[cat] = (w * 64) / p.tq + lane;
     }
 }
@@ -1214,7 +1216,8 @@ __global__ __launch_bounds__(kBlock) void k_brick_boxes_bm(const CarveParams p, 
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_brick_words(const CarveParams p, const BrickLists bl)
 {
     extern __shared__ uint32_t s_grid[];
-    uint32_t *cnt = bl.counters + bl.parity * 3 * kShards;
+    const uint64_t tr0 = (p.dbg & 32u) ? wall_clock64() : 0ull;
+    uint32_t *cnt = bl.counters + bl.parity * 3 * kShards * kShardStride;
     const ShardView sv = shard_view(cnt, 1, threadIdx.x & 63u);
     const uint32_t nlist = sv.total;
     if (blockIdx.x == 0 && threadIdx.x == 0) bl.host_counts[0] = nlist;
@@ -1233,6 +1236,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
     const uint32_t nwaves = gridDim.x * (kBlock / 64);
     const uint32_t qpl = p.nx >> 2, nzl = (uint32_t)(p.n / ((uint64_t)p.nx * p.ny));
+    const uint64_t tr1 = (p.dbg & 32u) ? wall_clock64() : 0ull;
     for (uint32_t t = wave0; t < nlist; t += nwaves) {
         uint32_t shard, within, ssize;
         shard_locate(sv, t, shard, within, ssize);
@@ -1242,7 +1246,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         bool cand = qx < qpl && izl < nzl;
         uint32_t need = 0;                                        // by camera NUMBER (k_voxel_words has no use for the order)
         const size_t slot = (size_t)b * 64 + lane;
-        for (uint32_t q0 = 0; q0 < p.C && __ballot(cand) != 0; q0 += 4) {
+        for (uint32_t q0 = 0; q0 < p.C && __ballot(cand) != 0 && !(p.dbg & 2u); q0 += 4) {
             uint64_t bb[4];
             uint32_t cn[4];
 #pragma unroll
@@ -1260,16 +1264,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             }
         }
         if (!cand) need = 0;
-        if (need == 0 || (p.dbg & 1u)) bl.bm[slot] = cand ? ~0ull : 0ull;         // decided here
+        const bool exists = qx < qpl && izl < nzl;
+        const uint64_t T = ((uint64_t)(exists ? izl : 0u) * qpl + (exists ? qx : 0u)) * p.tq + by;
+        if (exists && (need == 0 || (p.dbg & 1u))) bl.bm[T] = cand ? ~0ull : 0ull;     // decided here
         const uint64_t um = (p.dbg & 1u) ? 0ull : __ballot(need != 0);
         if (um) {
-            const size_t o = 2 * (size_t)shard_append(cnt + 2 * kShards, bl.cap_w, t % kShards, um, lane);
-            if (need) {
-                const uint64_t T = ((uint64_t)izl * qpl + qx) * p.tq + by;
-                bl.words[o] = T | ((uint64_t)need << 32);
-                bl.words[o + 1] = (uint64_t)slot;
-            }
+            const size_t o = shard_append(cnt + 2 * kShards * kShardStride, bl.cap_w, t % kShards, um, lane);
+            if (need) bl.words[o] = T | ((uint64_t)need << 32);
         }
+    }
+    if ((p.dbg & 32u) && lane == 0 && wave0 < 16384u) {
+        bl.trace[3 * wave0] = tr0; bl.trace[3 * wave0 + 1] = tr1; bl.trace[3 * wave0 + 2] = wall_clock64();
     }
 }
 
@@ -1279,7 +1284,7 @@ __global__ __launch_bounds__(kBlock) void k_voxel_words(const CarveParams p, con
 {
     constexpr int B = 8;
     const uint32_t lane = threadIdx.x & 63u;
-    const ShardView sv = shard_view(bl.counters + (bl.parity * 3 + 2) * kShards, B, lane);    // in batches of B words, per shard
+    const ShardView sv = shard_view(bl.counters + (bl.parity * 3 + 2) * kShards * kShardStride, B, lane);    // in batches of B words, per shard
     const uint32_t nbatch = sv.total;
     if (blockIdx.x == 0 && threadIdx.x == 0) bl.host_counts[2] = nbatch * B;
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
@@ -1291,8 +1296,8 @@ __global__ __launch_bounds__(kBlock) void k_voxel_words(const CarveParams p, con
         shard_locate(sv, t, shard, within, ssize);
         const bool mine_valid = lane < (uint32_t)B && within * B + lane < ssize;
         const size_t at = (size_t)shard * bl.cap_w + within * B + lane;
-        uint64_t e0 = 0, e1 = 0;
-        if (mine_valid) { e0 = bl.words[2 * at]; e1 = bl.words[2 * at + 1]; }
+        uint64_t e0 = 0;
+        if (mine_valid) e0 = bl.words[at];
         uint32_t nd[B], Tb[B];
         uint32_t alive = 0, ndany = 0;
 #pragma unroll
@@ -1359,42 +1364,52 @@ __global__ __launch_bounds__(kBlock) void k_voxel_words(const CarveParams p, con
             const uint64_t nb = __ballot((alive >> b) & 1u);
             if (lane == (uint32_t)b) mine = nb;
         }
-        if (mine_valid) bl.bm[e1] = mine;
+        if (mine_valid) bl.bm[(uint32_t)e0] = mine;
     }
 }
 
-// One wave per group (4096 consecutive voxels = 64 tile words gw .. gw + 63) of the listed brick columns.
+// One wave per (listed brick column, layer): the 4 / qpg groups (4096 consecutive voxels = 64 tile words each) that lie
+// side by side along x in that layer.  Their loads are issued together; the column's live / full bits are read once.
 __global__ __launch_bounds__(kBlock) void k_assemble(const CarveParams p, const BrickLists bl)
 {
     const uint32_t lane = threadIdx.x & 63u;
-    const ShardView sv = shard_view(bl.counters + (bl.parity * 3 + 1) * kShards, 1, lane);
+    const ShardView sv = shard_view(bl.counters + (bl.parity * 3 + 1) * kShards * kShardStride, 1, lane);
     const uint32_t ncols = sv.total;
     if (blockIdx.x == 0 && threadIdx.x == 0) bl.host_counts[1] = ncols;
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
     const uint32_t nwaves = gridDim.x * (kBlock / 64);
     const uint32_t qpl = p.nx >> 2, nzl = (uint32_t)(p.n / ((uint64_t)p.nx * p.ny));
     const uint32_t qpg = 64u / p.tq;                              // row quads per group (1, 2 or 4)
-    const uint32_t gq = 4u / qpg;                                 // groups along x inside a brick column
-    const uint32_t per_col = gq * 16u;
-    const uint32_t nunits = ncols * per_col;
+    const uint32_t gq = 4u / qpg;                                 // groups along x inside a brick column (4, 2 or 1)
+    const uint32_t nunits = ncols * 16u;
     const uint32_t nw = p.nbrick_pad >> 6;
+    const uint32_t dq = lane / p.tq, ty = lane - dq * p.tq;       // my tile word inside a group: row quad dq, tile column ty
     for (uint32_t u = wave0; u < nunits; u += nwaves) {
-        const uint32_t ci = u / per_col, r = u - ci * per_col, l = r / gq, xg = r - l * gq;     // wave-uniform
+        const uint32_t ci = u >> 4, l = u & 15u;                  // wave-uniform
         uint32_t shard, within, ssize;
         shard_locate(sv, ci, shard, within, ssize);
         const uint32_t col = hdr_u32(bl.columns, shard * bl.cap_c + within);
         const uint32_t bz = col / p.nbx, bx = col - bz * p.nbx;
-        const uint32_t izl = 16 * bz + l, qx0 = 4 * bx + xg * qpg;                                 // first row quad of the group
-        if (izl >= nzl || qx0 >= qpl) continue;
-        // lane: tile word (quad qx0 + lane / tq, column lane % tq)
-        const uint32_t dq = lane / p.tq, ty = lane - dq * p.tq, qx = qx0 + dq;
-        const uint32_t b = col * p.tq + ty;
+        const uint32_t izl = 16 * bz + l;
+        if (izl >= nzl) continue;
+        const uint32_t b = col * p.tq + ty;                       // my brick (the same for every group of the column)
         const uint64_t lw = p.live[b >> 6], fw = p.live[nw + (b >> 6)];
-        uint64_t mine = 0;
-        if (qx < qpl && ((lw >> (b & 63u)) & 1ull))
-            mine = ((fw >> (b & 63u)) & 1ull) ? ~0ull : bl.bm[(size_t)b * 64 + ((qx & 3u) << 4) + l];
-        const uint64_t gw = ((uint64_t)izl * qpl + qx0) * p.tq;   // first tile word of the group = 64 x its group number
-        tile_store(p, (uint32_t)(gw >> 6), gw, lane, mine);
+        const bool live = (lw >> (b & 63u)) & 1ull, full = (fw >> (b & 63u)) & 1ull;
+        uint64_t mine[4];
+#pragma unroll
+        for (uint32_t xg = 0; xg < 4; ++xg) {
+            const uint32_t qx0 = 4 * bx + xg * qpg;               // first row quad of group xg
+            const uint64_t gw = ((uint64_t)izl * qpl + qx0) * p.tq;
+            mine[xg] = (xg < gq && qx0 + dq < qpl && live) ? (full ? ~0ull : bl.bm[gw + lane]) : 0ull;
+        }
+#pragma unroll
+        for (uint32_t xg = 0; xg < 4; ++xg) {
+            const uint32_t qx0 = 4 * bx + xg * qpg;
+            if (xg < gq && qx0 < qpl) {
+                const uint64_t gw = ((uint64_t)izl * qpl + qx0) * p.tq;   // first tile word of the group = 64 x its group number
+                tile_store(p, (uint32_t)(gw >> 6), gw, lane, mine[xg]);
+            }
+        }
     }
 }
 

@@ -195,10 +195,11 @@ struct vc_ctx {
     DevBuf<uint64_t> d_live;         // per frame set: bit per brick "may hold survivors" | "all voxels survive" (k_cull)
     // brick pipeline (k_cull_bricks -> k_brick_words -> k_voxel_words -> k_assemble)
     DevBuf<uint64_t> d_wbox;         // [C][nbrick_pad * 64] brick-major word boxes (geometry only)
-    DevBuf<uint64_t> d_bm;           // [nbrick_pad * 64] brick-major tile-word results of the current step
+    DevBuf<uint64_t> d_bm;           // [n_pad / 64] tile-word results of the current step, tile order
     DevBuf<uint32_t> d_blist;        // counters [8] | brick list [nbrick_pad] | column list
-    DevBuf<uint64_t> d_wlist;        // undecided words, two u64 each (worst case: every word of the slab)
+    DevBuf<uint64_t> d_wlist;        // undecided words (worst case: every word of the slab)
     uint32_t *h_lists = nullptr;     // pinned [4]: list lengths of an earlier step, to size launches by
+    DevBuf<uint64_t> d_trace;        // experiments (dbg & 32)
     uint32_t list_parity = 0;
     int strips = 1;                  // carve by bricks where the grid shape allows (ny in {256, 512, 1024}); (option name kept)
     int dbg = 0;
@@ -398,12 +399,13 @@ int launch_bricks(vc_ctx *ctx, CarveParams &p, size_t lds, uint32_t ngroups)
     BrickLists bl;
     bl.cap_b = wps * 64; bl.cap_c = wps * 4;
     bl.cap_w = (p.nbrick_pad + kShards - 1) / kShards * 64;                   // a listed brick appends at most its 64 words
-    VC_TRY(ensure(ctx, ctx->d_bm, (size_t)p.nbrick_pad * 64));
-    VC_TRY(ensure(ctx, ctx->d_wlist, (size_t)bl.cap_w * kShards * 2));
-    const size_t need = 6 * kShards + (size_t)bl.cap_b * kShards + (size_t)bl.cap_c * kShards + 64;
+    VC_TRY(ensure(ctx, ctx->d_bm, (size_t)(p.n_pad / 64)));
+    VC_TRY(ensure(ctx, ctx->d_wlist, (size_t)bl.cap_w * kShards));
+    const size_t ncounters = 6 * (size_t)kShards * kShardStride;
+    const size_t need = ncounters + (size_t)bl.cap_b * kShards + (size_t)bl.cap_c * kShards + 64;
     if (ctx->d_blist.cap < need) {
         VC_TRY(ensure(ctx, ctx->d_blist, need));
-        VC_HIP(ctx, hipMemsetAsync(ctx->d_blist.ptr, 0, 6 * kShards * sizeof(uint32_t), ctx->stream));   // both sets of list lengths
+        VC_HIP(ctx, hipMemsetAsync(ctx->d_blist.ptr, 0, ncounters * sizeof(uint32_t), ctx->stream));    // both sets of list lengths
         ctx->list_parity = 0;
     }
     if (!ctx->h_lists) {
@@ -411,14 +413,19 @@ int launch_bricks(vc_ctx *ctx, CarveParams &p, size_t lds, uint32_t ngroups)
         ctx->h_lists[0] = ctx->h_lists[1] = ctx->h_lists[2] = ctx->h_lists[3] = 0xffffffffu;       // unknown yet
     }
     bl.counters = ctx->d_blist.ptr;
-    bl.bricks = ctx->d_blist.ptr + 6 * kShards;
+    bl.bricks = ctx->d_blist.ptr + ncounters;
     bl.columns = bl.bricks + (size_t)bl.cap_b * kShards;
     bl.words = ctx->d_wlist.ptr;
     bl.bm = ctx->d_bm.ptr;
     bl.wbox = ctx->d_wbox.ptr;
     bl.host_counts = ctx->h_lists;
     bl.parity = (ctx->list_parity ^= 1u);
-    (void)ncolumns;
+    bl.trace = nullptr;
+    if (ctx->dbg & 32) {
+        VC_TRY(ensure(ctx, ctx->d_trace, 3 * 16384));
+        VC_HIP(ctx, hipMemsetAsync(ctx->d_trace.ptr, 0, 3 * 16384 * sizeof(uint64_t), ctx->stream));
+        bl.trace = ctx->d_trace.ptr;
+    }
     p.live = ctx->d_live.ptr;
     const volatile uint32_t *known = ctx->h_lists;                // lengths of an earlier step (any size is correct: the waves stride)
     const uint32_t k_bricks = known[0], k_cols = known[1], k_words = known[2];
@@ -428,9 +435,8 @@ int launch_bricks(vc_ctx *ctx, CarveParams &p, size_t lds, uint32_t ngroups)
     hipLaunchKernelGGL(k_brick_words, dim3(sized(k_bricks, p.nbrick_pad / 8, p.nbrick_pad, 4)), block, lds, ctx->stream, p, bl);
     hipLaunchKernelGGL((k_voxel_words<LUT>), dim3(sized(k_words, (uint64_t)p.nbrick_pad * 4, (uint64_t)p.nbrick_pad * 64, 32)), block, 0,
                        ctx->stream, p, bl);
-    const uint32_t per_col = (4u / (64u / p.tq)) * 16u;
-    hipLaunchKernelGGL(k_assemble, dim3(sized(k_cols == 0xffffffffu ? k_cols : k_cols * per_col, (uint64_t)ncolumns * per_col / 4,
-                                              (uint64_t)ncolumns * per_col, 4)), block, 0, ctx->stream, p, bl);
+    hipLaunchKernelGGL(k_assemble, dim3(sized(k_cols == 0xffffffffu ? k_cols : k_cols * 16u, (uint64_t)ncolumns * 4, (uint64_t)ncolumns * 16, 4)),
+                       block, 0, ctx->stream, p, bl);
     VC_HIP(ctx, hipGetLastError());
     return VC_OK;
 }
@@ -830,7 +836,7 @@ int vc_destroy(vc_ctx *ctx)
         if (s.e_up) (void)hipEventDestroy(s.e_up);
     }
     for (int k = 0; k < 2; ++k) if (ctx->ev_h[k]) (void)hipEventDestroy(ctx->ev_h[k]);
-    release(ctx->d_axes); release(ctx->d_morph); release(ctx->d_lut); release(ctx->d_bbox); release(ctx->d_lut_tile); release(ctx->d_tbox); release(ctx->d_kbox); release(ctx->d_live); release(ctx->d_wbox); release(ctx->d_bm); release(ctx->d_blist); release(ctx->d_wlist);
+    release(ctx->d_axes); release(ctx->d_morph); release(ctx->d_lut); release(ctx->d_bbox); release(ctx->d_lut_tile); release(ctx->d_tbox); release(ctx->d_kbox); release(ctx->d_live); release(ctx->d_wbox); release(ctx->d_bm); release(ctx->d_blist); release(ctx->d_wlist); release(ctx->d_trace);
     for (StepBuf &b : ctx->sb) {
         release(b.words); release(b.groupcnt); release(b.groupoff); release(b.blocksum); release(b.blockoff); release(b.records);
         release(b.ent); release(b.mine); release(b.counts);
@@ -1573,12 +1579,27 @@ int vc_debug_counters(vc_ctx *ctx, uint64_t out[8])
     CarveParams p;
     fill_params(ctx, p);
     if (ctx->d_blist.ptr) {
-        uint32_t c[6 * kShards];
-        VC_HIP(ctx, hipMemcpy(c, ctx->d_blist.ptr, sizeof c, hipMemcpyDeviceToHost));
-        const uint32_t *q = c + ctx->list_parity * 3 * kShards;
-        for (uint32_t k = 0; k < kShards; ++k) { out[0] += q[k]; out[4] += q[kShards + k]; out[5] += q[2 * kShards + k]; }
+        std::vector<uint32_t> c(6 * (size_t)kShards * kShardStride);
+        VC_HIP(ctx, hipMemcpy(c.data(), ctx->d_blist.ptr, c.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        const uint32_t *q = c.data() + (size_t)ctx->list_parity * 3 * kShards * kShardStride;
+        for (uint32_t k = 0; k < kShards; ++k) {
+            out[0] += q[k * kShardStride]; out[4] += q[(kShards + k) * kShardStride]; out[5] += q[(2 * kShards + k) * kShardStride];
+        }
     }
-    if (ctx->d_live.ptr && ctx->kbox_valid) {
+    if ((ctx->dbg & 32) && ctx->d_trace.ptr) {
+        std::vector<uint64_t> tr(3 * 16384);
+        VC_HIP(ctx, hipMemcpy(tr.data(), ctx->d_trace.ptr, tr.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        uint64_t t0min = ~0ull, t2max = 0, sum_life = 0, max_life = 0, sum_stage = 0, nwv = 0;
+        for (size_t i = 0; i < 16384; ++i) {
+            if (!tr[3 * i + 2]) continue;
+            ++nwv;
+            t0min = tr[3 * i] < t0min ? tr[3 * i] : t0min; t2max = tr[3 * i + 2] > t2max ? tr[3 * i + 2] : t2max;
+            const uint64_t life = tr[3 * i + 2] - tr[3 * i];
+            sum_life += life; max_life = life > max_life ? life : max_life; sum_stage += tr[3 * i + 1] - tr[3 * i];
+        }
+        if (nwv) { out[6] = ((t2max - t0min) << 32) | (sum_life / nwv); out[7] = (max_life << 32) | (sum_stage / nwv); out[3] = nwv; }
+    }
+    if (ctx->d_live.ptr && ctx->kbox_valid && !(ctx->dbg & 32)) {
         const size_t nw = p.nbrick_pad / 64;
         std::vector<uint64_t> bits(2 * nw);
         VC_HIP(ctx, hipMemcpy(bits.data(), ctx->d_live.ptr, bits.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
