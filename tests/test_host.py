@@ -144,3 +144,18 @@ def test_balanced_slab_bounds():
         assert len(b) == G + 1 and b[0] == 0 and b[-1] == nz and all(b[i] <= b[i + 1] for i in range(G))
     with pytest.raises(ValueError):
         slabs.balanced_bounds([1.0, 2.0], 16, 128, 4)
+
+
+def test_drop_in_default_source_fails_early_and_by_name():
+    """Without a configured frame source and without cv2 / the reference's modules (this container, the GPU box),
+    set_voxel_positions raises ONE VoxcarveError that names configure(frame_source=...), before touching the GPU --
+    not an ImportError out of the viewer's key callback (reference call site: executable.py:185-188)."""
+    import importlib.util
+    if importlib.util.find_spec("cv2") is not None and importlib.util.find_spec("background_subtraction") is not None:
+        pytest.skip("the reference's acquisition modules are importable here")
+    from voxcarve import assignment
+    from voxcarve._lib import VoxcarveError
+    assignment.configure(frame_source=None)
+    with pytest.raises(VoxcarveError, match=r"configure\(frame_source"):
+        assignment.set_voxel_positions(8, 4, 8)
+    assert not assignment.initialized

@@ -14,6 +14,7 @@ import os
 
 import numpy as np
 
+from ._lib import VoxcarveError
 from .camera import load_cameras
 from .engine import (COLOR_CAMERA_INDEX, DEFAULT_BOUNDS, CarveEngine, viewer_colors, viewer_positions,
                      voxel_keys)
@@ -52,9 +53,18 @@ class ReferenceVideoSource:
         # post_on_device: leave the 2x2 open/close tail of extract_foreground_mask to the GPU
         # (CarveEngine.set_mask_postfilter with cam_bg_model_params[c][4:6]); masks then come out unfiltered.
         self.post_on_device = post_on_device
-        import cv2  # noqa: F401  (ImportError here means: install a frame source instead)
-        import background_subtraction
-        import utils
+        try:
+            import cv2
+            import background_subtraction
+            import utils
+        except ImportError as exc:
+            # fail HERE, once and by name -- not with a bare ImportError out of the viewer's key callback
+            raise VoxcarveError(
+                "voxcarve.assignment.set_voxel_positions has no frame source: the default one decodes the videos and "
+                "subtracts the background with the reference's own modules (cv2 / opencv-contrib, background_subtraction, "
+                "utils), and %r is not importable here.  Run from inside a reference checkout with OpenCV installed, or "
+                "call voxcarve.assignment.configure(frame_source=...) with an object whose next() returns "
+                "(frames, masks) or None (e.g. StaticFrameSource)." % exc.name) from exc
         self._bs = background_subtraction
         self.videos, self.bg_models = [], []
         for camera in range(num_cameras):

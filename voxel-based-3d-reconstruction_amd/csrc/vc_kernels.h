@@ -8,7 +8,7 @@
 // leave the kernels as y-major words.
 //
 //   per frame set   k_morph2x2 (optional), k_prep_pack, k_prep_grid: two launches, nothing returns to the host
-//   per geometry    k_build_lut<TILE> (table and/or word boxes), k_tile_lut
+//   per geometry    k_build_lut<TILE> (table and/or word boxes), k_brick_boxes_bm
 //   carve           k_lut_refine<B,HIER,PAIR,TILE>   hierarchical lookup-table kernel (default VC_MODE_LUT)
 //                   k_carve_fused_hier<TILE,BOX>     the same with the projection in-kernel (default VC_MODE_FUSED)
 //                   k_lut_first + k_lut_refine<.,false,.>   the table streamed without skipping (roofline_stream)
@@ -115,6 +115,7 @@ struct EmitParams {
     const uint32_t *maskbits;   // colour camera's mask bits (or null)
     const uint32_t *frame;      // colour camera's image as one BGRX dword per pixel (or null)
     const int32_t *lut;         // colour camera's packed table (FROM_LUT), else null
+    uint32_t lut_tq;            // != 0: that table is in TILE order (tile words per row quad = ny / 16); 0: y-major
     const uint64_t *words;
     const uint32_t *busylist;   // k_emit_busy: the groups with survivors; busycount[0] of them
     const uint32_t *busycount;
@@ -406,7 +407,7 @@ __device__ __forceinline__ void brick_bits(const CarveParams &p, uint64_t T, boo
 // 64 consecutive y.  A compact footprint has a pixel box of ~2 blocks instead of ~5, so the box test
 // decides more words (undecided 7 % -> 3.8 % in the hull's layers at 1024^3, scripts/exp_shapes.py).
 // Needs nx % 4 == 0 and ny % 64 == 0; the table and the boxes are kept in that order too
-// (k_tile_lut), and the wave transposes its 64 result words back to y-major before storing them.
+// (k_build_lut<true>), and the wave transposes its 64 result words back to y-major before storing them.
 template <int B, bool HIER, bool PAIR, bool TILE = false>
 __device__ __forceinline__ void lut_refine_body(const CarveParams &p, uint32_t vblock, uint32_t nblocks, uint32_t *s_grid)
 {
@@ -960,39 +961,6 @@ __global__ __launch_bounds__(kBlock) void k_build_lut(const CarveParams p, int32
         const bool inside = __ballot(off >= 0) == ~0ull;          // every voxel of the word lands in the image
         if (bbox && (threadIdx.x & 63u) == 0)
             bbox[(size_t)c * nwords + (j >> 6)] =
-                (u0 == 0xffffu) ? kEmptyBox
-                                : ((uint64_t)u0 | ((uint64_t)v0 << 16) | ((uint64_t)u1 << 32) | ((uint64_t)v1 << 48) |
-                                   (inside ? kBoxAllInside : 0ull));
-    }
-}
-
-// The table and the word boxes once more in tile order (see lut_refine_body<TILE>): element e of tile
-// word T is row r = e / 16 of its row quad, y = 16 * ty + e % 16.  A permutation of the linear table.
-__global__ __launch_bounds__(kBlock) void k_tile_lut(const CarveParams p, const int32_t *__restrict__ lut,
-                                                     int32_t *__restrict__ lut_tile, uint64_t *__restrict__ tbox)
-{
-    const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;      // grid covers n_pad exactly
-    const uint64_t T = t >> 6;
-    const uint32_t e = (uint32_t)t & 63u, r = e >> 4, yy = e & 15u;
-    const bool valid = t < p.n;
-    uint64_t j = 0;
-    if (valid) {
-        const uint32_t quad = (uint32_t)(T / p.tq), ty = (uint32_t)(T - (uint64_t)quad * p.tq);
-        const uint32_t qpl = p.nx >> 2;
-        const uint32_t izl = quad / qpl, qx = quad - izl * qpl;
-        j = ((uint64_t)izl * p.nx + qx * 4 + r) * p.ny + (uint64_t)ty * 16 + yy;
-    }
-    const uint64_t nwords = p.n_pad >> 6;
-    for (uint32_t c = 0; c < p.C; ++c) {
-        const int32_t off = valid ? lut[(size_t)c * p.n_pad + j] : -1;
-        lut_tile[(size_t)c * p.n_pad + t] = off;
-        const uint32_t pv = off >= 0 ? (uint32_t)off / p.W : 0u;
-        const uint32_t pu = off >= 0 ? (uint32_t)off - pv * p.W : 0u;
-        const uint32_t u0 = wave_min_u32(off >= 0 ? pu : 0xffffu), u1 = wave_max_u32(pu);
-        const uint32_t v0 = wave_min_u32(off >= 0 ? pv : 0xffffu), v1 = wave_max_u32(pv);
-        const bool inside = __ballot(off >= 0) == ~0ull;
-        if (e == 0)
-            tbox[(size_t)c * nwords + T] =
                 (u0 == 0xffffu) ? kEmptyBox
                                 : ((uint64_t)u0 | ((uint64_t)v0 << 16) | ((uint64_t)u1 << 32) | ((uint64_t)v1 << 48) |
                                    (inside ? kBoxAllInside : 0ull));
@@ -1856,6 +1824,14 @@ __global__ __launch_bounds__(kBlock) void k_finish_scan(const uint64_t *__restri
     }
 }
 
+// Slab-local voxel j -> its entry in a tile-ordered table (word T = 4 x-rows x 16 y of one z-layer, element = row * 16 + y).
+__device__ __forceinline__ uint32_t tile_index(uint32_t j, uint32_t nx, uint32_t ny, uint32_t tq)
+{
+    uint32_t ix, iy, izl;
+    decompose(j, nx, ny, ix, iy, izl);
+    return (((izl * (nx >> 2) + (ix >> 2)) * tq + (iy >> 4)) << 6) + ((ix & 3u) << 4) + (iy & 15u);
+}
+
 // r-th (0-based) set bit of x; requires r < popcount(x).
 __device__ __forceinline__ uint32_t select_bit(uint64_t x, uint32_t r)
 {
@@ -1917,7 +1893,7 @@ __device__ __forceinline__ void emit_body(const EmitParams &p, uint32_t vblock)
                 off[u] = -1;
                 if (p.has_cam) {
                     if (FROM_LUT) {
-                        off[u] = p.lut[j[u]];
+                        off[u] = p.lut[p.lut_tq ? tile_index(j[u], p.nx, p.ny, p.lut_tq) : j[u]];
                     } else {
                         uint32_t ix, iy, izl;
                         decompose(j[u], p.nx, p.ny, ix, iy, izl);
@@ -1972,14 +1948,16 @@ __device__ __forceinline__ void emit_group_lanes(const EmitParams &p, const uint
     }
     const uint32_t c = (uint32_t)__popcll(mine);
     const uint32_t wstart = wave_inclusive_scan(c, lane) - c;           // first record of my word in the group
+    // colour look-up in a TILE-ordered table: where my word's 64 entries start (4 runs of 16; all lanes at once, once per group)
+    const uint32_t tbase = (FROM_LUT && !INDIRECT && p.lut_tq) ? tile_index((uint32_t)((gw + lane) << 6), p.nx, p.ny, p.lut_tq) : 0u;
     const uint64_t below = (1ull << lane) - 1ull;
     uint64_t nz = __ballot(mine != 0);
     while (nz != 0) {                                                   // wave-uniform
-        uint32_t li[EB], ws[EB], jb[EB];
+        uint32_t li[EB], ws[EB], jb[EB], tb[EB];
         uint64_t wv[EB];
 #pragma unroll
         for (int b = 0; b < EB; ++b) {
-            li[b] = 0; wv[b] = 0; ws[b] = 0; jb[b] = 0;
+            li[b] = 0; wv[b] = 0; ws[b] = 0; jb[b] = 0; tb[b] = 0;
             if (nz != 0) {
                 li[b] = (uint32_t)__builtin_ctzll(nz);
                 nz &= nz - 1;
@@ -1989,6 +1967,7 @@ __device__ __forceinline__ void emit_group_lanes(const EmitParams &p, const uint
                 const uint32_t whi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), (int)li[b]);
                 wv[b] = ((uint64_t)whi << 32) | wlo;
                 ws[b] = (uint32_t)__builtin_amdgcn_readlane((int)wstart, (int)li[b]);
+                tb[b] = (uint32_t)__builtin_amdgcn_readlane((int)tbase, (int)li[b]);
             }
         }
         int32_t off[EB];
@@ -1998,7 +1977,9 @@ __device__ __forceinline__ void emit_group_lanes(const EmitParams &p, const uint
             if (p.has_cam && ((wv[b] >> lane) & 1ull)) {
                 const uint32_t j = jb[b] + lane;
                 if (FROM_LUT) {
-                    off[b] = p.lut[j];
+                    // (tile order: jb is a multiple of 64 and ny % 64 == 0, so the word's 64 voxels are 4 runs of 16 entries;
+                    // everything but the lane terms is wave-uniform)
+                    off[b] = p.lut[(!INDIRECT && p.lut_tq) ? tb[b] + ((lane >> 4) << 6) + (lane & 15u) : j];
                 } else {
                     uint32_t ix, iy, izl;
                     decompose(j, p.nx, p.ny, ix, iy, izl);

@@ -214,7 +214,8 @@ struct vc_ctx {
     int fused_f32box = 1;            // its word boxes from float32 intervals after a float64 rigid transform ...
     int fused_color_table = 0;       // VC_MODE_FUSED: colour the survivors from the colour camera's table (one camera, whole grid)
     int fused_boxes = 1;             // ... or read from boxes reduced once from the exact pixels (no table involved)
-    bool lut_valid = false;
+    bool lut_valid = false;          // vc_build_lut ran for this grid / slab / cameras (tile-ordered table, or y-major where tiles do not apply)
+    bool ymajor_valid = false;       // the y-major table + y-line boxes exist (built on demand: streaming / generic kernels, vc_fetch_lut)
     // tuning knobs (vc_set_option); defaults are the measured best on MI355X
     bool force_generic = false;      // one-thread-per-voxel kernels only (cross-check path)
     int first_kv = 1;                // dwordx4 loads per lane per chunk in k_lut_first: 1, 2 or 4
@@ -899,7 +900,7 @@ int vc_set_grid(vc_ctx *ctx, uint32_t nx, uint32_t ny, uint32_t nz, const double
     ctx->have_grid = true;
     for (Slot &sl : ctx->slots) sl.grids_valid = false;       // the camera order was sampled on the old geometry
     if (ctx->h_lists) ctx->h_lists[0] = ctx->h_lists[1] = ctx->h_lists[2] = 0xffffffffu;
-    ctx->lut_valid = false; ctx->bbox_valid = false; ctx->tbox_valid = false; ctx->kbox_valid = false; ctx->carved = false; ctx->gathered = false; ctx->viewmask_valid = false;
+    ctx->lut_valid = false; ctx->ymajor_valid = false; ctx->tile_valid = false; ctx->bbox_valid = false; ctx->tbox_valid = false; ctx->kbox_valid = false; ctx->carved = false; ctx->gathered = false; ctx->viewmask_valid = false;
     ctx->lut_color_cam = -1; ctx->packed = false;
     return VC_OK;
 }
@@ -912,7 +913,7 @@ int vc_set_slab(vc_ctx *ctx, uint32_t z0, uint32_t z1)
     if (z0 > z1 || z1 > ctx->nz) return fail(ctx, VC_ERR_ARG, "slab [%u,%u) outside [0,%u]", z0, z1, ctx->nz);
     ctx->z0 = z0; ctx->z1 = z1;
     for (Slot &sl : ctx->slots) sl.grids_valid = false;
-    ctx->lut_valid = false; ctx->bbox_valid = false; ctx->tbox_valid = false; ctx->kbox_valid = false; ctx->carved = false; ctx->gathered = false; ctx->viewmask_valid = false;
+    ctx->lut_valid = false; ctx->ymajor_valid = false; ctx->tile_valid = false; ctx->bbox_valid = false; ctx->tbox_valid = false; ctx->kbox_valid = false; ctx->carved = false; ctx->gathered = false; ctx->viewmask_valid = false;
     ctx->packed = false;
     return VC_OK;
 }
@@ -956,7 +957,7 @@ int vc_set_cameras(vc_ctx *ctx, uint32_t C, const double *K9, const double *dist
         for (Slot &s : ctx->slots) release_slot(s);
     }
     for (Slot &sl : ctx->slots) sl.grids_valid = false;
-    ctx->lut_valid = false; ctx->bbox_valid = false; ctx->tbox_valid = false; ctx->kbox_valid = false; ctx->carved = false; ctx->gathered = false; ctx->viewmask_valid = false;
+    ctx->lut_valid = false; ctx->ymajor_valid = false; ctx->tile_valid = false; ctx->bbox_valid = false; ctx->tbox_valid = false; ctx->kbox_valid = false; ctx->carved = false; ctx->gathered = false; ctx->viewmask_valid = false;
     ctx->lut_color_cam = -1; ctx->packed = false;
     return VC_OK;
 }
@@ -1056,6 +1057,27 @@ int vc_upload_frame(vc_ctx *ctx, uint32_t slot, uint32_t cam, const uint8_t *bgr
     return VC_OK;
 }
 
+// The y-major table [C][n_pad] (+ the y-line words' boxes): what the streaming and the one-thread-per-voxel kernels, the
+// y-line hierarchical kernel and vc_fetch_lut read.  The default kernels read the tile-ordered table only, so this one is
+// built when something first asks for it (19 ms at 1024^3 x 4, 17 GB).
+static int ensure_ymajor(vc_ctx *ctx)
+{
+    if (ctx->ymajor_valid) return VC_OK;
+    const uint64_t n = ctx->n_voxels();
+    const uint64_t n_pad = (n + kLutPad - 1) / kLutPad * kLutPad;
+    VC_TRY(ensure(ctx, ctx->d_lut, (size_t)n_pad * ctx->C));
+    VC_TRY(ensure(ctx, ctx->d_bbox, (size_t)(n_pad / 64) * ctx->C));
+    if (n) {
+        CarveParams p;
+        fill_params(ctx, p);
+        hipLaunchKernelGGL(k_build_lut<false>, dim3(grid_for(n_pad)), dim3(kBlock), 0, ctx->stream, p, ctx->d_lut.ptr, ctx->d_bbox.ptr);
+        VC_HIP(ctx, hipGetLastError());
+    }
+    ctx->bbox_valid = true;
+    ctx->ymajor_valid = true;
+    return VC_OK;
+}
+
 int vc_build_lut(vc_ctx *ctx)
 {
     if (!ctx) return VC_ERR_ARG;
@@ -1064,31 +1086,28 @@ int vc_build_lut(vc_ctx *ctx)
     VC_HIP(ctx, hipSetDevice(ctx->device));
     const uint64_t n = ctx->n_voxels();
     const uint64_t n_pad = (n + kLutPad - 1) / kLutPad * kLutPad;
-    VC_TRY(ensure(ctx, ctx->d_lut, (size_t)n_pad * ctx->C));
-    VC_TRY(ensure(ctx, ctx->d_bbox, (size_t)(n_pad / 64) * ctx->C));
-    if (n) {
-        CarveParams p;
-        fill_params(ctx, p);
-        VC_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-        hipLaunchKernelGGL(k_build_lut<false>, dim3(grid_for(n_pad)), dim3(kBlock), 0, ctx->stream, p, ctx->d_lut.ptr, ctx->d_bbox.ptr);
-        VC_HIP(ctx, hipGetLastError());
-        ctx->bbox_valid = true;
-        ctx->tile_valid = false;
-        if (ctx->lut_tile && ctx->nx % 4 == 0 && ctx->ny % 64 == 0) {
-            VC_TRY(ensure(ctx, ctx->d_lut_tile, (size_t)n_pad * ctx->C));
-            VC_TRY(ensure(ctx, ctx->d_tbox, (size_t)(n_pad / 64) * ctx->C));
+    VC_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    ctx->tile_valid = false;
+    if (ctx->lut_tile && ctx->nx % 4 == 0 && ctx->ny % 64 == 0) {
+        // ONE table, in tile order (words of 4 x-rows x 16 y), projected straight into that order; the colour look-up of
+        // the record expansion reads it too (closed-form index).  No y-major copy unless something asks for one.
+        VC_TRY(ensure(ctx, ctx->d_lut_tile, (size_t)n_pad * ctx->C));
+        VC_TRY(ensure(ctx, ctx->d_tbox, (size_t)(n_pad / 64) * ctx->C));
+        if (n) {
+            CarveParams p;
             fill_params(ctx, p);
-            hipLaunchKernelGGL(k_tile_lut, dim3(grid_for(n_pad)), dim3(kBlock), 0, ctx->stream, p, ctx->d_lut.ptr,
-                               ctx->d_lut_tile.ptr, ctx->d_tbox.ptr);
+            hipLaunchKernelGGL(k_build_lut<true>, dim3(grid_for(n_pad)), dim3(kBlock), 0, ctx->stream, p, ctx->d_lut_tile.ptr, ctx->d_tbox.ptr);
             VC_HIP(ctx, hipGetLastError());
             ctx->tile_valid = true;
             ctx->tbox_valid = true;
             VC_TRY(build_brick_boxes(ctx));
         }
-        VC_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-        VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.lut_ms, ctx->ev[0], ctx->ev[1]));
+    } else {
+        VC_TRY(ensure_ymajor(ctx));
     }
+    VC_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.lut_ms, ctx->ev[0], ctx->ev[1]));
     ctx->lut_valid = true;
     return VC_OK;
 }
@@ -1099,6 +1118,8 @@ int vc_fetch_lut(vc_ctx *ctx, uint32_t cam, int32_t *out)
     if (!ctx->lut_valid) return fail(ctx, VC_ERR_ARG, "no lookup table: call vc_build_lut");
     if (cam >= ctx->C) return fail(ctx, VC_ERR_ARG, "camera %u not in [0,%u)", cam, ctx->C);
     VC_HIP(ctx, hipSetDevice(ctx->device));
+    VC_TRY(ensure_ymajor(ctx));
+    VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const uint64_t n = ctx->n_voxels();
     const uint64_t n_pad = (n + kLutPad - 1) / kLutPad * kLutPad;
     if (n) VC_HIP(ctx, hipMemcpy(out, ctx->d_lut.ptr + (size_t)cam * n_pad, n * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -1177,7 +1198,6 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
 
     CarveParams p;
     fill_params(ctx, p);
-    p.lut = ctx->d_lut.ptr;
     p.words = sb.words.ptr;
     p.groupcnt = sb.groupcnt.ptr;
     p.viewmask = ctx->d_viewmask.ptr;
@@ -1197,6 +1217,11 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     VC_TRY(ensure_prepared(ctx, s, fast, &p));
     p.maskbits = s.bits.ptr;
     p.blockgrid = s.grid.ptr;
+    // which table the step reads: the tile-ordered one (hierarchical kernels on tile words), else the y-major one
+    const bool lut_tiled = mode == VC_MODE_LUT && fast && ctx->lut_hier && ctx->lut_tile && ctx->tile_valid;
+    if (mode == VC_MODE_LUT && !lut_tiled) VC_TRY(ensure_ymajor(ctx));
+    p.lut = ctx->d_lut.ptr;
+    p.bbox = ctx->d_bbox.ptr;
     const size_t grid_lds = ((size_t)s.budget_words + 8) * sizeof(uint32_t);
 
     VC_HIP(ctx, hipEventRecord(sb.e0, ctx->stream));
@@ -1360,7 +1385,11 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
         e.maskbits = s.bits.ptr + (size_t)color_cam * ctx->mwords;
         if (s.frames.ptr && s.have_frame[color_cam])
             e.frame = s.frames.ptr + (size_t)color_cam * ctx->H * ctx->W;
-        if (mode == VC_MODE_LUT) e.lut = ctx->d_lut.ptr + (size_t)color_cam * p.n_pad;
+        if (mode == VC_MODE_LUT && ctx->tile_valid && !ctx->ymajor_valid) {
+            e.lut = ctx->d_lut_tile.ptr + (size_t)color_cam * p.n_pad;      // the only table there is: tile order
+            e.lut_tq = p.tq;
+        }
+        else if (mode == VC_MODE_LUT) e.lut = ctx->d_lut.ptr + (size_t)color_cam * p.n_pad;
         else if (ctx->fused_color_table && !sb.no_records) {
             // table-free carve, but the colour look-up of the survivors reads the colour camera's table (4 B per
             // voxel of the whole grid, one camera) instead of projecting every survivor again
