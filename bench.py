@@ -1,28 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- visual-hull carve throughput on MI355X (BASELINE.json metric).
 
-One "step" = one pass of the hot path (reference voxel_reconstruction.py:89-124 +
-assignment.py:116-133) over one frame set whose byte masks + colour image are resident in HBM: per-frame preparation on
+One "step" = one pass of the hot path (reference voxel_reconstruction.py:89-124 + assignment.py:116-133)
+over one frame set whose byte masks + colour image are resident in HBM: per-frame preparation on
 the device (bit-pack, foreground boxes, cropped block grids, camera order, BGRX image -- two kernels, no host
-round trip) -> carve kernel -> scan -> ordered survivor records (+ RCCL all-gather when N > 1).  Cameras and
+round trip) -> carve kernels -> scan -> ordered survivor records (+ RCCL all-gather when N > 1).  Cameras and
 (LUT mode) the packed lookup table are built once, before the timed region.  Every timed step prepares its
 frame set again (vc_touch_masks): nothing derived from the masks is carried over from an earlier step.
 
-Workload (config.workload): BASELINE configs[2]/[3] -- 1024^3 grid x 4 cameras, block-split
-along z over the N ranks (STRONG scaling: the grid is fixed, as BASELINE's ">= 6x at 8 GPUs"
-is stated).  Inputs: the reference's 4 calibrated cameras and frame-0 MOG masks (committed
-fixtures), the masks rolled by a few columns per step so no two consecutive steps see the
-same input; synthetic colour frames.
+Workloads (config.name):
+  real     BASELINE configs[2]/[3] (default): 1024^3 grid x the reference's 4 calibrated cameras, frame-0 MOG mask
+           fixtures rolled by a few columns per frame set, synthetic colour frames.  N > 1: the grid is block-split
+           along z (STRONG scaling, as BASELINE's ">= 6x at 8 GPUs" is stated).
+  config5  BASELINE configs[4]: 512^3 x 16 synthetic ring cameras, 1080x1920 masks with 0.5 % salt noise, colour on.
+  big2048  2048 x 2048 x 1023 (4.29 G voxels, the u32 index limit) x the 4 real cameras, table-free mode: a case
+           for N > 1 where the carve kernels, not the record expansion, are most of a step.
 
-  python bench.py [--gpus N --steps K --warmup W] [--grid 1024] [--mode lut|fused]
+  python bench.py [--gpus N --steps K --warmup W] [--workload real|config5|big2048] [--grid 1024] [--mode lut|fused]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0.  `value` is the headline mode (default lut: the table-
-streaming form the reference's per-call function has, HBM-bound); the other mode is timed
-too and reported under "other_modes".  No framework is imported: for N > 1 the RCCL unique id
-travels through a node-local file and barriers / the max-over-ranks timing go through RCCL.
+Prints ONE JSON line on rank 0.  No framework is imported: for N > 1 the RCCL unique id travels through a
+node-local file and barriers / the max-over-ranks timing go through RCCL.  A rank that cannot join the RCCL
+communicator makes EVERY rank exit non-zero (no silent change of transport) unless --allow-host-fallback is given.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -35,8 +37,6 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-F64_VALU_PEAK_TFLOPS = 78.6    # half the 157.3 TF fp32 vector figure; no MFMA on this path
-FLOP_PER_VV = 52               # f64 flop per voxel-view of the fused form (+1 divide)
 LUT_BYTES_PER_VV = 4           # one packed int32 per voxel-view
 N_SLOTS = 8                    # resident frame sets (distinct byte masks); every timed step prepares its set again
 
@@ -46,17 +46,21 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--grid", type=int, default=1024)
-    ap.add_argument("--mode", choices=("lut", "lut_stream", "fused"), default="lut")
+    ap.add_argument("--workload", choices=("real", "config5", "big2048"), default="real")
+    ap.add_argument("--grid", type=int, default=1024, help="workload real: N of the N^3 grid")
+    ap.add_argument("--mode", choices=("lut", "lut_stream", "fused"), default=None,
+                    help="default: lut (real, config5), fused (big2048)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--prewarm-seconds", type=float, default=1.0,
-                    help="untimed launches before the W warm-up steps so the clocks have ramped (a cold device ran "
-                         "the same kernels up to 19 %% slower)")
+                    help="untimed launches before the W warm-up steps so the clocks have ramped")
     ap.add_argument("--depth", type=int, choices=(1, 2), default=2,
                     help="steps in flight: with 2, step i+1 is queued on the device before the host collects step i")
     ap.add_argument("--transport", choices=("rccl", "host"), default="rccl",
                     help="N>1 survivor exchange: rccl (device, default) or host (gloo; rehearsal on one GPU)")
+    ap.add_argument("--allow-host-fallback", action="store_true",
+                    help="N>1: if the RCCL communicator cannot be created, continue on a /dev/shm host transport (and say so) "
+                         "instead of exiting non-zero")
     ap.add_argument("--exchange", choices=("compact", "records"), default="compact",
                     help="N>1 over RCCL: exchange the non-zero occupancy words and expand on every rank (default), "
                          "or the 8-byte survivor records themselves")
@@ -68,6 +72,7 @@ def parse():
     ap.add_argument("--resident-prep", action="store_true",
                     help="steady state of round 1: frame sets prepared once, outside the timed region (default: every timed "
                          "step prepares its frame set on the device)")
+    ap.add_argument("--only-headline", action="store_true", help="skip the other modes and the side measurements")
     ap.add_argument("--e2e-steps", type=int, default=5, help="steps of the PCIe-inclusive leg (0: skip it)")
     return ap.parse_args()
 
@@ -102,7 +107,7 @@ class Group:
         self.eng = eng
 
     def attach_fallback(self, transport):
-        """RCCL unavailable: barriers and reductions through the /dev/shm exchange."""
+        """RCCL unavailable and --allow-host-fallback: barriers and reductions through the /dev/shm exchange."""
         self.shm = transport
 
     def barrier(self):
@@ -132,13 +137,37 @@ class Group:
             self.shm.close()
 
 
-def run_mode(eng, grp, mode, steps, warmup, multi, host_transport=None, depth=2, exchange="compact", overlap=1, fresh=True):
-    """W untimed + K timed steps of one mode; returns (seconds, kernel ms avg, survivors, total).
+def make_workload(args):
+    """(grid, cameras, masks, frames, colour camera, default mode, text)."""
+    import fixtures_util as fx
+    if args.workload == "config5":
+        from voxcarve import synthetic
+        H, W, C = 1080, 1920, 16
+        cams = synthetic.ring_cameras(C, H, W)
+        masks = synthetic.ellipsoid_masks(cams, H, W)          # 0.5 % salt noise, as SURVEY 8(d) specifies
+        frames = synthetic.random_frames(C, H, W)
+        return (512, 512, 512), cams, masks, frames, 1, "lut", \
+            "BASELINE config 5: 512^3 x 16 synthetic ring cameras, ellipsoid silhouettes XOR 0.5 % salt noise, colour on"
+    cams, masks = fx.golden_cameras(), fx.golden_masks()
+    frames = fx.synthetic_frames(len(cams), *masks[0].shape)
+    if args.workload == "big2048":
+        return (2048, 2048, 1023), cams, masks, frames, 1, "fused", \
+            "2048x2048x1023 grid (u32 index limit) x the 4 real cameras, table-free"
+    G = args.grid
+    return (G, G, G), cams, masks, frames, 1, "lut", "%d^3 voxel grid x the reference's 4 calibrated cameras" % G
+
+
+def run_mode(eng, grp, mode, steps, warmup, multi, host_transport=None, depth=2, exchange="compact", overlap=1, fresh=True,
+             detail=False, cc=1):
+    """W untimed + K timed steps of one mode; returns (seconds, survivors of this rank, total, timing dict).
     overlap: the scan + record expansion of a step on a second stream, beside the next step's carve (the product's
-    default).  lut_stream exists to measure ONE kernel against the HBM roof, so it always runs on one stream."""
-    eng.set_option("lut_hier", 0 if mode == "lut_stream" else 1)
-    eng.set_option("overlap", 0 if mode == "lut_stream" else overlap)
-    mode = "lut" if mode == "lut_stream" else mode
+    default).  lut_stream exists to measure ONE kernel against the HBM roof, so it runs on one stream with its events on.
+    detail: also record the events around preparation and carve kernels (they cost the stream ~10 us each)."""
+    stream = mode == "lut_stream"
+    eng.set_option("lut_hier", 0 if stream else 1)
+    eng.set_option("overlap", 0 if stream else overlap)
+    eng.set_option("timing_detail", 1 if (detail or stream) else 0)
+    mode = "lut" if stream else mode
 
     def finish():
         n = eng.carve_end()
@@ -167,11 +196,11 @@ def run_mode(eng, grp, mode, steps, warmup, multi, host_transport=None, depth=2,
         slot = i % N_SLOTS
         if fresh:
             eng.touch_masks(slot)
-        eng.carve_begin(slot=slot, mode=mode, records=keep)
+        eng.carve_begin(slot=slot, mode=mode, records=keep, color_cam=cc)
 
     def run(first, count):
         """`count` steps; with depth 2 step i+1 is enqueued before step i is collected, so the device
-        never idles between steps (one stream, same kernels)."""
+        never idles between steps."""
         last = (0, 0)
         if depth <= 1:
             for i in range(count):
@@ -195,36 +224,46 @@ def run_mode(eng, grp, mode, steps, warmup, multi, host_transport=None, depth=2,
     grp.barrier()
     dt = grp.max(time.perf_counter() - t0)
     tm = eng.timing()
-    kernel_ms = tm["carve_ms_sum"] / max(1, tm["carve_launches"])
-    return dt, kernel_ms, last[0], last[1], tm
+    eng.set_option("timing_detail", 0)
+    return dt, last[0], last[1], tm
 
 
-def cpu_baseline(grid, cams, masks, frames, seconds):
+def cpu_baseline(grid, cams, masks, frames, seconds, cc, device_digest=None):
     """The C/OpenMP oracle ("port") on this host's cores: the WHOLE grid of the same workload when that
-    fits the time budget (a few seconds on a many-core host), else a centred z-slab sized to it."""
+    fits the time budget (a few seconds on a many-core host), else a centred z-slab sized to it.  When it is the
+    whole grid, its record list is also the checker of the device's (sha256 of the packed records)."""
     import fixtures_util as fx
     from oracle import carve_c
     oc = fx.oracle_cams(cams)
+    nx, ny, nz = grid
     threads = len(os.sched_getaffinity(0))
-    layer = grid * grid
-    carve_c.carve(grid, grid, grid, oc, masks, frames, index_range=(0, layer * 2), threads=threads, cap=1 << 22)   # warm the pool
-    probe = max(1, min(grid, 16))
-    z_mid = grid // 2
+    layer = nx * ny
+    carve_c.carve(nx, ny, nz, oc, masks, frames, index_range=(0, layer * 2), threads=threads, cap=1 << 22, color_cam=cc)   # warm the pool
+    probe = max(1, min(nz, 16))
+    z_mid = nz // 2
     t0 = time.perf_counter()
-    carve_c.carve(grid, grid, grid, oc, masks, frames, index_range=(z_mid * layer, (z_mid + probe) * layer),
-                  threads=threads, cap=1 << 22)
+    carve_c.carve(nx, ny, nz, oc, masks, frames, index_range=(z_mid * layer, (z_mid + probe) * layer),
+                  threads=threads, cap=1 << 22, color_cam=cc)
     per_layer = (time.perf_counter() - t0) / probe
-    layers = int(max(1, min(grid, seconds / max(per_layer, 1e-9))))
-    z0 = max(0, (grid - layers) // 2)
+    layers = int(max(1, min(nz, seconds / max(per_layer, 1e-9))))
+    z0 = max(0, (nz - layers) // 2)
     t0 = time.perf_counter()
-    res = carve_c.carve(grid, grid, grid, oc, masks, frames, index_range=(z0 * layer, (z0 + layers) * layer),
-                        threads=threads, cap=1 << 26)
+    res = carve_c.carve(nx, ny, nz, oc, masks, frames, index_range=(z0 * layer, (z0 + layers) * layer),
+                        threads=threads, cap=1 << 27, color_cam=cc)
     dt = time.perf_counter() - t0
     vv = layers * layer * len(cams)
-    what = "the whole %d^3 grid" % grid if layers == grid else "z-layers [%d,%d) of the %d^3 grid" % (z0, z0 + layers, grid)
-    return {"value": round(vv / dt / 1e6, 2), "unit": "Mvoxel-views/s", "cores": threads, "kind": "port",
-            "sample": "oracle/carve_ref.c (C/OpenMP, -O2 -ffp-contract=off), %s, %.3g voxel-views in %.2f s, "
-                      "%d survivors" % (what, vv, dt, res["count"])}
+    whole = layers == nz
+    what = "the whole %dx%dx%d grid" % grid if whole else "z-layers [%d,%d) of the %dx%dx%d grid" % ((z0, z0 + layers) + grid)
+    out = {"value": round(vv / dt / 1e6, 2), "unit": "Mvoxel-views/s", "cores": threads, "kind": "port",
+           "sample": "oracle/carve_ref.c (C/OpenMP, -O2 -ffp-contract=off), %s, %.3g voxel-views in %.2f s, "
+                     "%d survivors" % (what, vv, dt, res["count"])}
+    if whole and device_digest is not None:
+        bgr = res["bgr"].astype(np.uint64)
+        rec = res["idx"].astype(np.uint64) | (bgr[:, 2] << np.uint64(32)) | (bgr[:, 1] << np.uint64(40)) \
+            | (bgr[:, 0] << np.uint64(48)) | (np.uint64(1) << np.uint64(56))
+        out["records_sha256"] = hashlib.sha256(rec.tobytes()).hexdigest()
+        out["device_records_match"] = out["records_sha256"] == device_digest
+    return out
 
 
 def main():
@@ -232,95 +271,169 @@ def main():
     import voxcarve
     voxcarve._lib.load()                 # libvoxcarve (system HIP runtime) is loaded before any torch import
     grp = Group(args.gpus, use_torch=(args.transport == "host"))
-    import fixtures_util as fx
     from voxcarve import slabs
 
-    cams, masks = fx.golden_cameras(), fx.golden_masks()
+    grid, cams, masks, frames, cc, default_mode, workload_text = make_workload(args)
+    if args.mode is None:
+        args.mode = default_mode
     H, W = masks[0].shape
     C = len(cams)
-    frames = fx.synthetic_frames(C, H, W)
-    G = args.grid
-    grid = (G, G, G)
+    nx, ny, nz = grid
 
     eng = voxcarve.CarveEngine(0 if args.single_device else grp.local_rank)
     eng.set_grid(*grid)
-    z0, z1 = slabs.slab_range(G, grp.world, grp.rank)
+    z0, z1 = slabs.slab_range(nz, grp.world, grp.rank)
     eng.set_slab(z0, z1)
     eng.set_cameras(cams, H, W)
     for s in range(N_SLOTS):
         eng.upload_masks([np.roll(m, 3 * s, axis=1) for m in masks], slot=s)
-        eng.upload_frame(1, np.roll(frames[1], 3 * s, axis=1), slot=s)
+        eng.upload_frame(cc, np.roll(frames[cc], 3 * s, axis=1), slot=s)
     multi = grp.world > 1 or args.force_comm
     host_transport = None
+    rccl_ranks = 0
     transport_note = ("rccl, %s" % ("non-zero occupancy words, expanded on every rank" if args.exchange == "compact"
                                     else "8-byte survivor records")) if multi else "none (one rank)"
     if multi and args.transport == "host":
         host_transport = slabs.TorchTransport()
         transport_note = "host (gloo) rehearsal"
     elif multi:
+        # the decision "RCCL or not" is COLLECTIVE: every rank reports how its communicator set-up went through the
+        # rendezvous directory and all act on the same list -- a rank that failed alone cannot wander off to another
+        # transport while the others sit in a collective
+        err = ""
         try:
             uid = slabs.file_rendezvous(grp.rank, voxcarve.CarveEngine.comm_unique_id() if grp.rank == 0 else None)
             eng.comm_init(grp.world, grp.rank, uid)
+        except Exception as exc:
+            err = str(exc)[:300] or type(exc).__name__
+        flags = slabs.file_all_flags(grp.rank, grp.world, "comm", err)
+        if all(f == "" for f in flags):
             grp.attach(eng)
             grp.barrier()
-            slabs.file_rendezvous_cleanup(grp.rank)
-        except Exception as exc:      # no communicator: say so and still deliver a (slow) measured exchange
-            transport_note = "shm-fallback: RCCL communicator unavailable (%s)" % str(exc)[:200]
+            rccl_ranks = grp.world
+        else:
+            why = "; ".join("rank %d: %s" % (r, f) for r, f in enumerate(flags) if f)
+            if not args.allow_host_fallback:
+                sys.stderr.write("[bench rank %d] RCCL communicator unavailable (%s); no --allow-host-fallback: exiting\n" % (grp.rank, why))
+                slabs.file_rendezvous_cleanup(grp.rank, grp.world)
+                eng.close()
+                raise SystemExit(3)
+            transport_note = "shm-fallback (--allow-host-fallback): RCCL communicator unavailable (%s)" % why[:200]
             sys.stderr.write("[bench rank %d] %s\n" % (grp.rank, transport_note))
+            if not err:
+                eng.comm_destroy()
             host_transport = slabs.ShmTransport(grp.world, grp.rank)
             grp.attach_fallback(host_transport)
+        slabs.file_rendezvous_cleanup(grp.rank, grp.world)
     split_note = "even"
     if grp.world > 1 and args.split == "balanced":
         # the hull is not spread evenly over z: give every rank the same share of measured kernel time
         chunk = 16
-        weights = slabs.measure_chunk_cost(eng, G, chunk, reduce_max=grp.max)
-        bounds = slabs.balanced_bounds(weights, chunk, G, grp.world)
+        weights = slabs.measure_chunk_cost(eng, nz, chunk, mode="fused" if args.mode == "fused" else "lut", reduce_max=grp.max,
+                                           color_cam=cc)
+        bounds = slabs.balanced_bounds(weights, chunk, nz, grp.world)
         z0, z1 = bounds[grp.rank], bounds[grp.rank + 1]
         split_note = "balanced by measured chunk cost: z bounds %s" % bounds
     eng.set_slab(z0, z1)
-    eng.build_lut()
+    have_lut = args.workload != "big2048" and not (args.mode == "fused" and args.only_headline)
+    if have_lut:
+        eng.build_lut()
     eng.synchronize()
-    lut_ms = eng.timing()["lut_ms"]
+    lut_ms = eng.timing()["lut_ms"] if have_lut else 0.0
     h2d_ms = eng.timing()["h2d_ms"]           # the last frame set's byte masks over PCIe (asynchronous, on the upload stream)
 
     t_end = time.perf_counter() + args.prewarm_seconds
     while time.perf_counter() < t_end:
-        eng.carve(slot=0, mode="fused")
+        eng.carve(slot=0, mode="fused", color_cam=cc)
+    short = max(10, args.steps // 5)
+    common = dict(multi=multi, host_transport=host_transport, depth=args.depth, exchange=args.exchange, cc=cc)
     results = {}
-    order = [args.mode] + [m for m in ("lut", "lut_stream", "fused") if m != args.mode]
+    order = [args.mode]
+    if not args.only_headline and have_lut:
+        order += [m for m in ("lut", "lut_stream", "fused") if m != args.mode]
     for mode in order:
-        dt, kernel_ms, n_local, n_total, tm = run_mode(eng, grp, mode, args.steps, args.warmup, multi, host_transport, args.depth, args.exchange,
-                                                       fresh=not args.resident_prep)
-        results[mode] = {"seconds": dt, "kernel_ms": kernel_ms, "survivors": int(n_total),
-                         "preps": tm["preps"],
-                         "compact_ms": tm["compact_ms"], "gather_ms": tm["gather_ms_sum"] / max(1, tm["gathers"]),
-                         "exchange_ms": tm["exchange_ms"], "tm": tm}
-
-    # the dominant kernel of the headline mode without a neighbour: the same steps on one stream (short, untimed for `value`)
-    if not multi:                       # (a rank of a communicator runs on one stream anyway)
-        alone = run_mode(eng, grp, args.mode, max(10, args.steps // 5), 2, multi, host_transport, args.depth, args.exchange, overlap=0,
-                         fresh=not args.resident_prep)
-        results[args.mode]["kernel_ms_alone"] = alone[1]
-        results[args.mode]["ms_per_step_one_stream"] = alone[0] / max(10, args.steps // 5) * 1e3
-        eng.set_option("overlap", 1)
-        # the same steps once more with the per-frame preparation timed (one more event per step on the carve stream:
-        # kept out of the run `value` comes from)
-        eng.set_option("timing_detail", 1)
-        det = run_mode(eng, grp, args.mode, max(10, args.steps // 5), 2, multi, host_transport, args.depth, args.exchange,
-                       fresh=not args.resident_prep)
-        eng.set_option("timing_detail", 0)
-        results[args.mode]["prep_ms"] = det[4]["prep_ms_sum"] / max(1, det[4]["preps_timed"])
-        if not args.resident_prep:
-            res = run_mode(eng, grp, args.mode, max(10, args.steps // 5), 2, multi, host_transport, args.depth, args.exchange, fresh=False)
-            results[args.mode]["ms_per_step_resident_prep"] = res[0] / max(10, args.steps // 5) * 1e3
-    n_local_vox = eng.n_voxels
-    total_vv = float(G) ** 3 * C
+        dt, n_local, n_total, tm = run_mode(eng, grp, mode, args.steps, args.warmup, fresh=not args.resident_prep, **common)
+        results[mode] = {"seconds": dt, "survivors": int(n_total), "survivors_this_rank": int(n_local), "tm": tm}
     head = results[args.mode]
+
+    # side measurements of the headline mode (short runs, never `value`)
+    if not multi and not args.only_headline:
+        alone = run_mode(eng, grp, args.mode, short, 2, overlap=0, fresh=not args.resident_prep, detail=True, **common)
+        head["one_stream"] = {"ms_per_step": alone[0] / short * 1e3, "tm": alone[3]}
+        det = run_mode(eng, grp, args.mode, short, 2, fresh=not args.resident_prep, detail=True, **common)
+        head["detail"] = {"ms_per_step": det[0] / short * 1e3, "tm": det[3]}
+        if not args.resident_prep:
+            res = run_mode(eng, grp, args.mode, short, 2, fresh=False, **common)
+            head["ms_per_step_resident_prep"] = res[0] / short * 1e3
+    n_local_vox = eng.n_voxels
+    total_vv = float(nx) * ny * nz * C
     ms_per_step = head["seconds"] / args.steps * 1e3
     value = total_vv * args.steps / head["seconds"] / 1e6
 
-    # roofline of the DOMINANT kernel of the headline mode, on THIS rank's launches
-    vv_launch = float(n_local_vox) * C
+    # ---- the records of frame set 0, as a digest: all ranks must hold the same list, and rank 0 at N = 1 checks it against
+    # the CPU oracle's (cpu_baseline) and against the committed digest of an oracle-checked run
+    eng.set_option("overlap", 1)
+    eng.set_option("lut_hier", 1)
+    eng.set_option("gather_sync", 1)
+    counts_note = None
+    keep = not (multi and args.exchange == "compact")
+    eng.carve_begin(slot=0, mode="lut" if args.mode == "lut_stream" else args.mode, records=keep, color_cam=cc)
+    n_mine = eng.carve_end()
+    if multi and host_transport is None:
+        counts, n_all = eng.allgather()
+        rec = eng.fetch_gathered()
+        counts_note = [int(c) for c in counts]
+    elif multi and args.exchange == "compact":
+        n_all = eng.expand_entries(host_transport.allgather_entries(eng.pack_entries()))
+        rec = eng.fetch_gathered()
+    elif multi:
+        _, n_all = host_transport.allgather_records(eng.fetch_records(pinned=True))
+        rec = host_transport.fetch()
+    else:
+        n_all, rec = n_mine, eng.fetch_records(pinned=True)
+    digest = hashlib.sha256(np.ascontiguousarray(rec).tobytes()).hexdigest()
+    d48 = float(int(digest[:12], 16))                       # 48 bits: exact in a double
+    same = (grp.max(d48) == d48) and (-grp.max(-d48) == d48)
+    ranks_agree = grp.max(0.0 if same else 1.0) == 0.0
+    golden_file = os.path.join(ROOT, "tests", "golden", "bench_digests.json")
+    golden = json.load(open(golden_file)) if os.path.exists(golden_file) else {}
+    gkey = "%s_%dx%dx%d" % (args.workload, nx, ny, nz)
+    golden_match = (golden[gkey]["records_sha256"] == digest and golden[gkey]["survivors"] == int(n_all)) if gkey in golden else None
+
+    # ---- roofline of the DOMINANT kernel of the timed region.  With the carve cut into culling + word + voxel + assembly
+    # launches (0.01-0.03 ms each), the largest single kernel of a step is the record expansion k_emit_busy: it writes the packed
+    # survivor list (8 B per survivor) and reads each survivor's table entry (4 B, LUT mode) besides the occupancy words --
+    # HBM-bound.  Its launches are bracketed by the two events the streams exchange anyway (vc_timing emit_ms), over the timed region.
+    tm = head["tm"]
+    emit_ms = tm["emit_ms_sum"] / tm["emit_launches"] if tm["emit_launches"] else None
+    per_survivor = 8 + (4 if args.mode != "fused" else 0)
+    roof = None
+    if emit_ms:
+        alg = per_survivor * float(head["survivors_this_rank"])
+        ach = alg / (emit_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "k_emit_busy<%s> (record expansion: occupancy words -> ordered {idx, rgb, seen} records)" %
+                ("FROM_LUT" if args.mode != "fused" else "re-projecting"),
+                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                "algorithmic_bytes_per_launch": alg, "bytes_per_unit": "%d B per survivor (8 B record written%s)" %
+                (per_survivor, " + 4 B table entry read" if args.mode != "fused" else ""),
+                "units_per_launch": head["survivors_this_rank"], "avg_launch_ms": round(emit_ms, 4),
+                "timed_by": "HIP events e_scan (carve stream) .. e2 (expansion stream) of every timed step"}
+    elif multi and tm["gathers"]:
+        # a rank of a communicator expands the gathered words of ALL ranks (k_emit_lanes<INDIRECT>) inside vc_allgather
+        g_ms = tm["gather_ms_sum"] / tm["gathers"]
+        x_ms = tm["exchange_ms"]
+        alg = per_survivor * float(head["survivors"])
+        ach = alg / (max(g_ms - x_ms, 1e-6) * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "k_emit_lanes<INDIRECT> (expansion of all ranks' occupancy words on every rank)",
+                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(g_ms - x_ms, 4)}
+    # the contract's own figure for the whole step (4 B per voxel-view + 8 B per survivor + the masks): how much
+    # of the table the hierarchy never touches -- a skip factor, not a bandwidth
+    contract_bytes = LUT_BYTES_PER_VV * total_vv + 8.0 * head["survivors"] + C * H * W
+    skip = {"contract_bytes_per_step": contract_bytes, "rate_gbs": round(contract_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+            "skip_factor_vs_hbm_peak": round(contract_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
+            "note": "SURVEY 8(d) bytes of the streaming formulation / step time / 8 TB/s; > 1 because culling decides most of the "
+                    "grid from brick and word pixel boxes without reading its table entries"}
 
     def stream_roofline(r):
         # k_lut_first streams ONE camera's packed table over every voxel of the slab:
@@ -331,101 +444,88 @@ def main():
         return {"bound": "hbm", "kernel": "k_lut_first (first-camera table stream, LDS-resident mask)",
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                 "traffic": None, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(first_ms, 4),
-                "frac_of_measured_copy_ceiling_6290": round(ach / 6290.0, 4),
-                "carve_ms_stream_plus_refine": round(r["kernel_ms"], 4)}
+                "frac_of_measured_copy_ceiling_6290": round(ach / 6290.0, 4)}
 
-    if args.mode == "lut":
-        # k_lut_refine<.,HIER>: the whole carve in one launch.  By SURVEY 8(d)'s contract the algorithmic
-        # bytes are 4 B per voxel-view; the kernel rejects most 64-voxel words from an 8-byte pixel box
-        # per camera and never reads their table entries, so achieved exceeds the HBM peak: frac > 1
-        # measures the skipped work, `traffic` (PMC) is what really crossed the HBM interface.
-        alg_bytes = LUT_BYTES_PER_VV * vv_launch
-        achieved = alg_bytes / (head["kernel_ms"] * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "k_lut_refine<8,HIER,PAIR,TILE> (pixel-box x block-grid reject/accept per 64-voxel word, exact test for undecided words)",
-                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(head["kernel_ms"], 4),
-                "note": "frac > 1: hierarchical skipping, not bandwidth; the pure streaming form of the same "
-                        "table is in roofline_stream (k_lut_first, traffic == algorithmic bytes)"}
-    elif args.mode == "lut_stream":
-        roof = stream_roofline(head)
-    else:
-        achieved = FLOP_PER_VV * vv_launch / (head["kernel_ms"] * 1e-3) / 1e12
-        roof = {"bound": "valu_f64", "kernel": "k_carve_fused_hier<TILE,2> (word rejection/acceptance from per-word pixel boxes, in-kernel fp64 projection for undecided words)", "achieved": round(achieved, 3),
-                "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F64_VALU_PEAK_TFLOPS, 4),
-                "traffic": None, "avg_launch_ms": round(head["kernel_ms"], 4),
-                "note": "52 f64 flop per voxel-view counted for ALL voxel-views; most 64-voxel words are decided "
-                        "from the pixel box of the word (8 B per word and camera, reduced once per camera set) and never "
-                        "projected voxel by voxel"}
-    if not multi:
-        roof["concurrency"] = ("two steps in flight on two streams: the record expansion of the previous step runs beside this "
-                               "kernel, which stretches its launches (avg_launch_ms, as rocprofv3 sees them too) while the step "
-                               "gets shorter; on one stream the kernel takes avg_launch_ms_alone and the step ms_per_step_one_stream")
-        roof["avg_launch_ms_alone"] = round(head["kernel_ms_alone"], 4)
-        roof["ms_per_step_one_stream"] = round(head["ms_per_step_one_stream"], 4)
+    # (masks above 64 KB of bits per camera do not fit k_lut_first's LDS: that configuration takes the generic kernel)
+    roof_stream = stream_roofline(results["lut_stream"]) if "lut_stream" in results and (H * W + 31) // 32 * 4 <= 65536 else None
+    if args.mode == "lut_stream" and roof_stream:
+        roof = roof_stream
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-    roof_stream = stream_roofline(results["lut_stream"]) if args.mode != "lut_stream" else None
-    if os.path.exists(traffic_file):
+    if os.path.exists(traffic_file) and roof is not None:
         tj = json.load(open(traffic_file))
-        t = tj.get("%s_%d_g%d" % (args.mode, G, grp.world))
+        t = tj.get("emit_%s_%s_g%d" % (args.mode, gkey, grp.world))
         if t:
             roof["traffic"] = t
-            # the same launch priced by the bytes that really crossed the HBM interface (PMC) instead of the contract's
-            # algorithmic bytes: how busy the memory system is, as opposed to how much work was avoided
             gbs = t["hbm_bytes"] / (roof["avg_launch_ms"] * 1e-3) / 1e9
             roof["traffic_rate_gbs"] = round(gbs, 1)
             roof["traffic_frac_of_peak"] = round(gbs / HBM_PEAK_GBS, 4)
-        if roof_stream and tj.get("lut_stream_%d_g%d" % (G, grp.world)):
-            roof_stream["traffic"] = tj["lut_stream_%d_g%d" % (G, grp.world)]
+        if roof_stream and tj.get("lut_stream_%s_g%d" % (gkey, grp.world)):
+            roof_stream["traffic"] = tj["lut_stream_%s_g%d" % (gkey, grp.world)]
 
     others = {}
     for m in results:
         if m != args.mode:
             o = results[m]
             others[m] = {"value": round(total_vv * args.steps / o["seconds"] / 1e6, 1),
-                         "ms_per_step": round(o["seconds"] / args.steps * 1e3, 4),
-                         "kernel_ms": round(o["kernel_ms"], 4), "survivors": o["survivors"]}
+                         "ms_per_step": round(o["seconds"] / args.steps * 1e3, 4), "survivors": o["survivors"]}
+    phases = {"record_expansion": round(emit_ms, 4) if emit_ms else None,
+              "gather": round(tm["gather_ms_sum"] / max(1, tm["gathers"]), 4), "gather_exchange_part": round(tm["exchange_ms"], 4),
+              "lut_build_once": round(lut_ms, 3), "steps_that_prepared": int(tm["preps"]),
+              "mask_upload_h2d_outside_timed_region": round(h2d_ms, 4)}
+    if "detail" in head:
+        d, o = head["detail"]["tm"], head["one_stream"]["tm"]
+        phases.update({
+            "frame_set_prep_on_device": round(d["prep_ms_sum"] / max(1, d["preps_timed"]), 4),
+            "carve_kernels": round(d["carve_ms_sum"] / max(1, d["carve_launches"]), 4),
+            "carve_kernels_one_stream": round(o["carve_ms_sum"] / max(1, o["carve_launches"]), 4),
+            "record_expansion_one_stream": round(o["emit_ms_sum"] / max(1, o["emit_launches"]), 4),
+            "ms_per_step_one_stream": round(head["one_stream"]["ms_per_step"], 4),
+            "ms_per_step_with_kernel_events": round(head["detail"]["ms_per_step"], 4),
+            "note": "prep / carve figures come from a short extra run with the events around those kernels switched on "
+                    "(timing_detail): an event between two kernels costs the stream ~10 us, so the run `value` comes from "
+                    "records only the two events the streams exchange anyway"})
+    if head.get("ms_per_step_resident_prep") is not None:
+        phases["ms_per_step_with_frame_sets_prepared_once"] = round(head["ms_per_step_resident_prep"], 4)
     out = {
         "metric": "Mvoxel-views/s (grid N^3 x 4 cams)", "value": round(value, 1), "unit": "Mvoxel-views/s",
         "n_gpus": grp.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64" if args.mode == "fused" else "i32",
-        "data": "reference calibration (4x config.xml) + frame-0 MOG mask fixtures rolled per step; synthetic colour frames",
-        "config": {"workload": "%d^3 voxel grid x %d cams (%dx%d masks), z-slab split over %d GPU(s), mode=%s, "
-                               "ordered survivor list + colour%s" % (G, C, W, H, grp.world, args.mode,
+        "data": ("reference calibration (4x config.xml) + frame-0 MOG mask fixtures rolled per frame set; synthetic colour frames"
+                 if args.workload != "config5" else
+                 "synthetic ring cameras, ellipsoid silhouettes XOR 0.5 % salt noise rolled per frame set, random colour frames"),
+        "config": {"workload": "%s (%dx%d masks), z-slab split over %d GPU(s), mode=%s, per-frame preparation on the device + "
+                               "ordered survivor list + colour%s" % (workload_text, W, H, grp.world, args.mode,
                                                                      (" + RCCL all-gather" if host_transport is None else " + host-side gather") if multi else ""),
-                   "grid": [G, G, G], "cameras": C, "mode": args.mode, "survivors": head["survivors"],
-                   "steps_in_flight": args.depth, "exchange": transport_note, "split": split_note},
+                   "name": args.workload, "grid": [nx, ny, nz], "cameras": C, "mode": args.mode, "survivors": head["survivors"],
+                   "steps_in_flight": args.depth, "exchange": transport_note, "rccl_ranks": rccl_ranks, "split": split_note,
+                   "survivors_per_rank": counts_note, "records_sha256_frame_set_0": digest, "survivors_frame_set_0": int(n_all),
+                   "ranks_agree_on_records": bool(ranks_agree), "matches_committed_digest": golden_match},
         "roofline": roof,
+        "contract_skip": skip,
         "roofline_stream": roof_stream,
         "other_modes": others,
-        "phases_ms": {"carve_kernels": round(head["kernel_ms"], 4), "compact": round(head["compact_ms"], 4),
-                      "gather": round(head["gather_ms"], 4), "gather_exchange_part": round(head["exchange_ms"], 4),
-                      "lut_build_once": round(lut_ms, 3),
-                      "frame_set_prep_on_device": round(head.get("prep_ms", 0.0), 4),
-                      "steps_that_prepared": int(head["preps"]),
-                      "mask_upload_h2d_outside_timed_region": round(h2d_ms, 4)},
+        "phases_ms": phases,
     }
-    if head.get("ms_per_step_resident_prep") is not None:
-        out["phases_ms"]["ms_per_step_with_frame_sets_prepared_once"] = round(head["ms_per_step_resident_prep"], 4)
     if args.e2e_steps > 0 and grp.world == 1 and not args.force_comm:
         # PCIe-inclusive rate (never `value`): "writes a packed surviving-voxel list (+ sampled colour) back to host".
         # Per step: byte masks + colour frame up (page-locked staging, upload stream, beside the previous carve),
         # preparation + carve on the device, the records down into a page-locked buffer.
-        rolled = [[np.roll(m, 3 * s, axis=1) for m in masks] for s in range(N_SLOTS)]
+        rolled = [[np.roll(m, 3 * s, axis=1) for m in masks] for s in range(2)]
         K = args.e2e_steps
-        eng.carve(slot=0, mode=args.mode)
+        e2e_mode = "lut" if args.mode == "lut_stream" else args.mode
+        eng.carve(slot=0, mode=e2e_mode, color_cam=cc)
         eng.fetch_records(pinned=True)          # allocate the page-locked read-back buffer once
         eng.synchronize()
         t0 = time.perf_counter()
         eng.upload_masks(rolled[0], slot=0)
-        eng.upload_frame(1, frames[1], slot=0)
-        eng.carve_begin(slot=0, mode=args.mode)
+        eng.upload_frame(cc, frames[cc], slot=0)
+        eng.carve_begin(slot=0, mode=e2e_mode, color_cam=cc)
         for i in range(1, K + 1):
             if i < K:                            # the next frame set goes up and is queued while this one is collected
-                eng.upload_masks(rolled[i % N_SLOTS], slot=i % 2)
-                eng.upload_frame(1, frames[1], slot=i % 2)
-                eng.carve_begin(slot=i % 2, mode=args.mode)
+                eng.upload_masks(rolled[i % 2], slot=i % 2)
+                eng.upload_frame(cc, frames[cc], slot=i % 2)
+                eng.carve_begin(slot=i % 2, mode=e2e_mode, color_cam=cc)
             eng.carve_end()
             rec = eng.fetch_records(pinned=True)
         dt = (time.perf_counter() - t0) / K
@@ -434,14 +534,23 @@ def main():
                                  "bytes_up_per_step": int(C * H * W + H * W * 3),
                                  "note": "host byte masks + colour frame in, packed survivor records (8 B each) out, per step; "
                                          "the read-back of %.0f MB is the PCIe-bound part" % (rec.nbytes / 1e6)}
+    rc = 0
     if grp.rank == 0 and grp.world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(G, cams, masks, frames, args.cpu_seconds)
+        out["cpu_baseline"] = cpu_baseline(grid, cams, masks, frames, args.cpu_seconds, cc, device_digest=digest)
+        if out["cpu_baseline"].get("device_records_match") is False:
+            sys.stderr.write("[bench] device records differ from the CPU oracle's\n")
+            rc = 4
     elif grp.rank == 0:
         out["cpu_baseline"] = None
+    if not ranks_agree or golden_match is False:
+        sys.stderr.write("[bench rank %d] record digest check failed: ranks agree %s, committed digest %s\n" % (grp.rank, ranks_agree, golden_match))
+        rc = 4
     eng.close()
     grp.close()
     if grp.rank == 0:
         print(json.dumps(out))
+    if rc:
+        raise SystemExit(rc)
 
 
 if __name__ == "__main__":

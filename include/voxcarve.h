@@ -55,7 +55,10 @@ enum {
 #define VC_UNIQUE_ID_BYTES 128
 
 typedef struct {
-    float carve_ms;     /* the carve kernel alone (HIP events on the context's stream) */
+    float carve_ms;     /* the carve kernels alone (HIP events on the context's stream).  carve_ms, first_ms, compact_ms
+                           and prep_ms are measured for vc_carve calls and, with option timing_detail = 1, for
+                           vc_carve_begin steps: an event between two kernels costs the stream ~10 us, so pipelined
+                           steps record only the events they need anyway (emit_ms comes from those) */
     float compact_ms;   /* scan + emit kernels                                         */
     float gather_ms;    /* RCCL all-gather (vc_allgather)                              */
     float lut_ms;       /* last vc_build_lut                                           */
@@ -74,6 +77,9 @@ typedef struct {
     float prep_ms_sum;  /* summed since vc_timing_reset                                  */
     uint32_t preps;     /* carve steps that had to prepare their frame set since vc_timing_reset */
     uint32_t preps_timed; /* ... of which prep_ms_sum holds the time                     */
+    float emit_ms;      /* record expansion of the last step (events the two streams exchange anyway) */
+    float emit_ms_sum;  /* summed since vc_timing_reset                                  */
+    uint32_t emit_launches;
 } vc_timing_t;
 
 /* ---- lifetime ------------------------------------------------------------------ */
@@ -178,8 +184,8 @@ int vc_fetch_occupancy(vc_ctx *ctx, uint8_t *bits);
  *                   refine_b (8), refine_blocks_per_cu (8), fused_blocks_per_cu (8)
  *   streams         overlap (1)  scan + record expansion of a step on a second stream, beside the next step's carve
  *                                  (single stream while a communicator is attached)
- *   timing          timing_detail (0)  1: vc_timing's prep_ms is measured (an extra event per step on the carve stream;
- *                                  an event between two kernels costs the stream ~10 us, so it is off by default)
+ *   timing          timing_detail (0)  1: vc_carve_begin steps record the events around preparation and carve kernels too
+ *                                  (vc_carve always does; see vc_timing_t)
  *   multi-GPU       gather_compact (1)  exchange occupancy words instead of records;
  *                   gather_sync (1)  0: vc_allgather returns once its work is queued
  * Unknown names or out-of-range values return VC_ERR_ARG. */

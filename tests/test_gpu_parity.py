@@ -805,6 +805,9 @@ def _run_bench(args, nproc=1, timeout=300):
                 "--master-port", str(port)]
     cmd += [os.path.join(root, "bench.py"), "--gpus", str(nproc)] + args
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=root)
+    if expect_rc is not None:
+        assert out.returncode != 0, "bench.py was expected to fail"
+        return out
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -826,9 +829,15 @@ def test_bench_contract_single_gpu(built):
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert d["config"]["survivors"] == 461113                      # the 256^3 golden count: the bench ran the real path
+    assert r["frac"] <= 1.0 and "k_emit_busy" in r["kernel"] and r["avg_launch_ms"] > 0
+    assert d["contract_skip"]["skip_factor_vs_hbm_peak"] > 0
+    # the device's record list of frame set 0 is the CPU oracle's, byte for byte (the baseline leg carved the whole grid)
+    assert c["device_records_match"] is True and c["records_sha256"] == d["config"]["records_sha256_frame_set_0"]
+    assert d["config"]["survivors_frame_set_0"] == 461113 and d["config"]["ranks_agree_on_records"] is True
     # every timed step prepared its frame set on the device, inside the timed region; the PCIe-inclusive figure is there
     ph = d["phases_ms"]
     assert ph["steps_that_prepared"] == 7 and 0 < ph["frame_set_prep_on_device"] < d["ms_per_step"]
+    assert 0 < ph["carve_kernels"] < d["ms_per_step"] and ph["record_expansion"] > 0
     assert d["pcie_inclusive"]["value"] > 0 and d["pcie_inclusive"]["value"] < d["value"]
 
 
@@ -844,6 +853,21 @@ def test_bench_two_ranks_host_transport(built):
     assert d["config"]["survivors"] == 461113
     for m in d["other_modes"].values():
         assert m["survivors"] == 461113
+    assert d["config"]["ranks_agree_on_records"] is True and d["config"]["survivors_frame_set_0"] == 461113
+    assert d["config"]["rccl_ranks"] == 0
+
+
+def test_bench_rccl_failure_is_collective_and_loud(built):
+    """Two ranks on ONE device: RCCL refuses the duplicate device.  Without --allow-host-fallback every rank exits non-zero
+    (no JSON line, no silently different transport); with it the run completes on the /dev/shm transport and says so."""
+    out = _run_bench(["--grid", "256", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--single-device", "--only-headline"],
+                     nproc=2, timeout=600, expect_rc=True)
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert "RCCL communicator unavailable" in out.stderr
+    d = _run_bench(["--grid", "256", "--steps", "8", "--warmup", "1", "--no-cpu-baseline", "--single-device", "--only-headline",
+                    "--allow-host-fallback"], nproc=2, timeout=600)
+    assert "shm-fallback" in d["config"]["exchange"] and d["config"]["rccl_ranks"] == 0
+    assert d["config"]["survivors"] == 461113 and d["config"]["ranks_agree_on_records"] is True
 
 
 def test_property_random_shapes_cameras_masks(eng):

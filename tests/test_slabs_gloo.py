@@ -112,3 +112,40 @@ def test_shm_fallback_transport(tmp_path):
     world = 3
     mp.spawn(_shm_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / ("ok_%d.npy" % r)).exists() for r in range(world))
+
+
+def _rdzv_worker(rank, world, port, out_dir, fail_rank):
+    os.environ["MASTER_PORT"] = str(port)
+    from voxcarve import slabs
+    uid = slabs.file_rendezvous(rank, b"U" * 128 if rank == 0 else None, timeout=30)
+    flags = slabs.file_all_flags(rank, world, "comm", "boom on %d" % rank if rank == fail_rank else "", timeout=30)
+    slabs.file_rendezvous_cleanup(rank, world)
+    with open(os.path.join(out_dir, "r%d" % rank), "w") as f:
+        f.write(repr((uid == b"U" * 128, flags)))
+
+
+@pytest.mark.parametrize("fail_rank", [None, 2])
+def test_rendezvous_decision_is_collective(tmp_path, fail_rank):
+    """bench.py's "did the RCCL set-up work everywhere?" without a communicator: the unique id reaches every rank, every
+    rank sees the same list of per-rank outcomes (so all of them fall back, or all exit), a file a dead process left under
+    the same key is ignored, and the directory is gone afterwards."""
+    import multiprocessing as mp
+    import struct
+    from voxcarve import slabs
+    port = _free_port()
+    os.environ["MASTER_PORT"] = str(port)
+    d = slabs._launch_dir(os.getpid())           # the workers are children of THIS process: that is their launch key
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, "uid"), "wb") as f:                       # left behind by a launch that crashed: writer pid is dead
+        f.write(struct.pack("<q", 2 ** 22 + 12345) + b"S" * 128)
+    ctx = mp.get_context("fork")
+    procs = [ctx.Process(target=_rdzv_worker, args=(r, 3, port, str(tmp_path), fail_rank)) for r in (1, 2, 0)]   # rank 0 starts last
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    seen = [eval(open(os.path.join(str(tmp_path), "r%d" % r)).read()) for r in range(3)]
+    want = ["", "", ""] if fail_rank is None else ["", "", "boom on 2"]
+    assert all(ok and flags == want for ok, flags in seen), seen
+    assert not os.path.exists(d)

@@ -38,7 +38,8 @@ class VcTiming(ctypes.Structure):
                 ("first_ms_sum", ctypes.c_float), ("exchange_ms", ctypes.c_float),
                 ("gather_ms_sum", ctypes.c_float), ("gathers", ctypes.c_uint32),
                 ("prep_ms", ctypes.c_float), ("prep_ms_sum", ctypes.c_float), ("preps", ctypes.c_uint32),
-                ("preps_timed", ctypes.c_uint32)]
+                ("preps_timed", ctypes.c_uint32), ("emit_ms", ctypes.c_float), ("emit_ms_sum", ctypes.c_float),
+                ("emit_launches", ctypes.c_uint32)]
 
 
 # name -> (restype, argtypes); every symbol include/voxcarve.h declares.

@@ -142,6 +142,8 @@ struct StepBuf {
     uint64_t *h_total = nullptr;             // pinned
     hipEvent_t e0 = nullptr, e_first = nullptr, e1 = nullptr, e2 = nullptr, e_scan = nullptr, e_prep = nullptr;
     bool prepped = false, prep_timed = false; // this step queued preparation kernels in front of its carve (timed: e_prep .. e0)
+    bool carve_timed = false;                // e0 / e1 were recorded around the carve kernels (synchronous calls, timing_detail)
+    bool emit_timed = false;                 // e_scan / e2 bracket the record expansion
     bool pending = false, used = false;
     EmitParams emit;                         // kept for a re-run after a records regrow
     bool allseen = false, want_vm = false, has_first = false;
@@ -231,7 +233,8 @@ struct vc_ctx {
     int emit_waves_per_cu = 256;     // waves of that launch per CU (a wave strides over the list when there are more busy groups)
     int fused_hier = 1;              // VC_MODE_FUSED: interval-arithmetic word rejection (needs ny % 64 == 0)
     int lut_hier = 1;                // VC_MODE_LUT: hierarchical kernel (boxes + block grid) instead of stream + refine
-    int timing_detail = 0;           // also time the per-frame preparation of each step (one more event on the carve stream)
+    int timing_detail = 0;           // also time preparation and carve kernels of pipelined steps (three more events on the carve stream)
+    bool sync_call = false;          // inside vc_carve: the step is collected at once, events between its kernels cost nothing that matters
     DevBuf<uint16_t> d_viewmask;
     DevBuf<double> d_scratch;
     uint64_t *h_total = nullptr;     // pinned scalar (all-gather count)
@@ -1211,7 +1214,8 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     if (mode == VC_MODE_LUT && !ctx->lut_hier && (size_t)ctx->mwords * sizeof(uint32_t) > kMaxFirstLds) fast = false;
     // per-frame preparation, on the device, in front of the carve (nothing to do when the slot has been used before)
     sb.prepped = !s.bits_valid || (fast && !s.grids_valid);
-    sb.prep_timed = sb.prepped && ctx->timing_detail;
+    sb.carve_timed = ctx->timing_detail || ctx->sync_call;
+    sb.prep_timed = sb.prepped && sb.carve_timed;
     if (sb.prep_timed) VC_HIP(ctx, hipEventRecord(sb.e_prep, ctx->stream));
     const bool read_bytes = !s.bits_valid;
     VC_TRY(ensure_prepared(ctx, s, fast, &p));
@@ -1224,7 +1228,7 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     p.bbox = ctx->d_bbox.ptr;
     const size_t grid_lds = ((size_t)s.budget_words + 8) * sizeof(uint32_t);
 
-    VC_HIP(ctx, hipEventRecord(sb.e0, ctx->stream));
+    if (sb.carve_timed) VC_HIP(ctx, hipEventRecord(sb.e0, ctx->stream));
     const dim3 block(kBlock);
     if (fast) {
         const uint64_t nchunks = (n + 64 * kSub - 1) / (64 * kSub);
@@ -1273,8 +1277,7 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
             else if (kv == 4) hipLaunchKernelGGL((k_lut_first<4>), fgrid, fblock, lds, ctx->stream, p);
             else hipLaunchKernelGGL((k_lut_first<2>), fgrid, fblock, lds, ctx->stream, p);
             VC_HIP(ctx, hipGetLastError());
-            VC_HIP(ctx, hipEventRecord(sb.e_first, ctx->stream));
-            sb.has_first = true;
+            if (sb.carve_timed) { VC_HIP(ctx, hipEventRecord(sb.e_first, ctx->stream)); sb.has_first = true; }
             const uint64_t groups = p.n_pad / 4096;
             const uint64_t rwant = (groups + 3) / 4;
             const uint64_t rmax = 256ull * (uint64_t)ctx->refine_blocks_per_cu;
@@ -1334,8 +1337,7 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
         }
     }
     VC_HIP(ctx, hipGetLastError());
-    VC_HIP(ctx, hipEventRecord(sb.e1, ctx->stream));
-    if (read_bytes) { s.e_read = sb.e1; s.read_pending = true; }   // an upload into this slot waits for the kernels that read its bytes
+    if (sb.carve_timed) VC_HIP(ctx, hipEventRecord(sb.e1, ctx->stream));
 
     // ---- compaction: group counts -> two-level scan -> record expansion
     // the carve kernels are VALU-issue bound, the expansion is memory bound: on its own stream the expansion of this
@@ -1400,9 +1402,12 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     e.records = sb.records.ptr;
     e.capacity = sb.records.cap;
     e.busylist = sb.busylist.ptr; e.busycount = sb.busyblock.ptr;
-    if (s3 != ctx->stream && !sb.no_records) {
-        VC_HIP(ctx, hipEventRecord(sb.e_scan, ctx->stream));
-        VC_HIP(ctx, hipStreamWaitEvent(s3, sb.e_scan, 0));
+    sb.emit_timed = false;
+    if (!sb.no_records && (s3 != ctx->stream || sb.carve_timed)) {
+        VC_HIP(ctx, hipEventRecord(sb.e_scan, ctx->stream));     // cross-stream dependency; with e2 it also brackets the expansion
+        if (s3 != ctx->stream) VC_HIP(ctx, hipStreamWaitEvent(s3, sb.e_scan, 0));
+        sb.emit_timed = true;
+        if (read_bytes) { s.e_read = sb.e_scan; s.read_pending = true; }   // an upload into this slot waits for the kernels that read its bytes
     }
     if (!sb.no_records) {
         VC_TRY(launch_emit(ctx, sb, s3));
@@ -1414,6 +1419,7 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     }
     VC_HIP(ctx, hipEventRecord(sb.e2, sb.no_records ? s2 : s3));
     if (!sb.no_records && s3 != ctx->stream) { s.e_emit = sb.e2; s.emit_pending = true; }   // the expansion reads the slot's bits / images
+    if (read_bytes && !s.read_pending) { s.e_read = sb.e2; s.read_pending = true; }          // (no e_scan recorded: e2 is behind the preparation too)
     sb.pending = true;
     sb.used = true;
     ctx->head ^= 1;
@@ -1444,16 +1450,22 @@ int vc_carve_end(vc_ctx *ctx, uint64_t *n_out)
             VC_HIP(ctx, hipEventSynchronize(sb.e2));
         }
         sb.survivors = total;
-        float ms = 0;
-        VC_HIP(ctx, hipEventElapsedTime(&ms, sb.e0, sb.e1));
-        ctx->tm.carve_ms = ms;
-        ctx->tm.first_ms = 0;
-        if (sb.has_first) VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.first_ms, sb.e0, sb.e_first));
-        else ctx->tm.first_ms = ms;                       // one kernel does the whole carve
-        ctx->tm.first_ms_sum += ctx->tm.first_ms;
-        ctx->tm.carve_ms_sum += ms;
-        ctx->tm.carve_launches += 1;
-        VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.compact_ms, sb.e1, sb.e2));
+        if (sb.carve_timed) {
+            float ms = 0;
+            VC_HIP(ctx, hipEventElapsedTime(&ms, sb.e0, sb.e1));
+            ctx->tm.carve_ms = ms;
+            ctx->tm.first_ms = ms;                               // one kernel sequence does the whole carve ...
+            if (sb.has_first) VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.first_ms, sb.e0, sb.e_first));   // ... unless a streaming first pass was timed
+            ctx->tm.first_ms_sum += ctx->tm.first_ms;
+            ctx->tm.carve_ms_sum += ms;
+            ctx->tm.carve_launches += 1;
+            VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.compact_ms, sb.e1, sb.e2));
+        }
+        if (sb.emit_timed) {
+            VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.emit_ms, sb.e_scan, sb.e2));
+            ctx->tm.emit_ms_sum += ctx->tm.emit_ms;
+            ctx->tm.emit_launches += 1;
+        }
         ctx->tm.prep_ms = 0;
         if (sb.prepped) ctx->tm.preps += 1;
         if (sb.prep_timed) {
@@ -1482,7 +1494,10 @@ int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int 
     if (!ctx || !n_out) return VC_ERR_ARG;
     *n_out = 0;
     if (ctx->npending != 0) return fail(ctx, VC_ERR_ARG, "vc_carve with steps in flight: drain them with vc_carve_end");
-    VC_TRY(vc_carve_begin(ctx, slot, min_views, color_cam, mode, flags));
+    ctx->sync_call = true;
+    const int rc = vc_carve_begin(ctx, slot, min_views, color_cam, mode, flags);
+    ctx->sync_call = false;
+    if (rc != VC_OK) return rc;
     return vc_carve_end(ctx, n_out);
 }
 
@@ -1661,6 +1676,8 @@ int vc_timing_reset(vc_ctx *ctx)
     ctx->tm.prep_ms_sum = 0;
     ctx->tm.preps = 0;
     ctx->tm.preps_timed = 0;
+    ctx->tm.emit_ms_sum = 0;
+    ctx->tm.emit_launches = 0;
     return VC_OK;
 }
 

@@ -8,10 +8,11 @@ lists IS the reference's output order (assignment.py:121-133).  One process per 
 one collective is a variable-length all-gather of 8-byte survivor records, done by RCCL
 over xGMI inside libvoxcarve (vc_allgather).  The reference has no distributed code.
 
-A ``Transport`` moves the records between ranks:
-  RcclTransport   device-to-device via the engine's RCCL communicator (the product path)
+The product path is device-to-device: CarveEngine.comm_init / allgather (RCCL inside libvoxcarve).  Host-side
+transports move the same data for rehearsals and tests:
   TorchTransport  host tensors via a torch.distributed process group (gloo) -- exercises the
                   same split / merge logic on CPU-only machines (tests)
+  ShmTransport    /dev/shm files, bench.py --allow-host-fallback only
 """
 import numpy as np
 
@@ -104,21 +105,6 @@ def merge_rank_entries(per_rank_entries):
     return out
 
 
-class RcclTransport:
-    """All-gather on the device through the engine's communicator (vc_comm_init / vc_allgather)."""
-
-    def __init__(self, engine, n_ranks, rank, uid):
-        self.engine = engine
-        engine.comm_init(n_ranks, rank, uid)
-
-    def allgather_records(self, local_records_unused=None):
-        counts, total = self.engine.allgather()
-        return counts, total
-
-    def fetch(self):
-        return self.engine.fetch_gathered()
-
-
 class TorchTransport:
     """Variable-length all-gather of host records over a torch.distributed group (gloo)."""
 
@@ -156,21 +142,52 @@ class TorchTransport:
         return self._gathered
 
 
+def _launch_dir(ppid=None):
+    """Node-local directory of THIS launch: keyed by the launcher's PID *and its start time* (identical for all ranks of one
+    launch, different for any other launch even when the PID is reused), MASTER_PORT and the elastic run id."""
+    import os
+    ppid = os.getppid() if ppid is None else ppid
+    try:
+        with open("/proc/%d/stat" % ppid) as f:
+            start = f.read().rsplit(")", 1)[1].split()[19]          # field 22: start time in clock ticks since boot
+    except OSError:
+        start = "0"
+    return os.path.join("/tmp", "voxcarve_rdzv_%d_%s_%s_%s" % (ppid, start, os.environ.get("MASTER_PORT", "0"),
+                                                              os.environ.get("TORCHELASTIC_RUN_ID", "none")))
+
+
+def _pid_alive(pid):
+    import os
+    try:
+        os.kill(pid, 0)
+        return True
+    except ProcessLookupError:
+        return False
+    except PermissionError:
+        return True
+
+
 def file_rendezvous(rank, payload=None, tag="uid", timeout=120.0):
     """One-shot broadcast from rank 0 through the node-local filesystem (one process per GPU on ONE
     node).  Used to hand the RCCL unique id to the other ranks without importing a framework: a
     process that uses vc_comm_* must not load a second ROCm runtime (torch wheels bundle their own
-    libhsa / librccl, and RCCL then resolves HSA from the wrong copy).  The directory is keyed by the
-    launcher's PID (identical for all ranks of one launch, unique per launch) and MASTER_PORT."""
+    libhsa / librccl, and RCCL then resolves HSA from the wrong copy).  The file starts with the writer's PID:
+    a reader ignores a file whose writer is no longer alive (left behind by a launch that crashed)."""
     import os
+    import struct
     import time
-    d = os.path.join("/tmp", "voxcarve_rdzv_%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0")))
+    d = _launch_dir()
     path = os.path.join(d, tag)
     if rank == 0:
         os.makedirs(d, exist_ok=True)
+        for name in os.listdir(d):                          # nothing of an earlier launch under the same key survives
+            try:
+                os.remove(os.path.join(d, name))
+            except OSError:
+                pass
         tmp = path + ".tmp"
         with open(tmp, "wb") as f:
-            f.write(payload)
+            f.write(struct.pack("<q", os.getpid()) + payload)
         os.replace(tmp, path)
         return payload
     t_end = time.time() + timeout
@@ -178,20 +195,60 @@ def file_rendezvous(rank, payload=None, tag="uid", timeout=120.0):
         try:
             with open(path, "rb") as f:
                 data = f.read()
-            if data:
-                return data
+            if len(data) > 8 and _pid_alive(struct.unpack("<q", data[:8])[0]):
+                return data[8:]
         except FileNotFoundError:
             pass
         time.sleep(0.002)
     raise TimeoutError("rendezvous file %s did not appear" % path)
 
 
-def file_rendezvous_cleanup(rank):
+def file_all_flags(rank, world, tag, text, timeout=180.0):
+    """Every rank posts a short text ("" = fine) under `tag`; returns the list of all ranks' texts, the same on every rank.
+    What makes a decision collective without a communicator: bench.py's "did the RCCL set-up work everywhere?"."""
+    import os
+    import time
+    d = _launch_dir()
+    os.makedirs(d, exist_ok=True)
+    tmp = os.path.join(d, "%s_%d.tmp" % (tag, rank))
+    with open(tmp, "w") as f:
+        f.write("%d\n%s" % (os.getpid(), text))
+    os.replace(tmp, os.path.join(d, "%s_%d" % (tag, rank)))
+    out = []
+    t_end = time.time() + timeout
+    for r in range(world):
+        path = os.path.join(d, "%s_%d" % (tag, r))
+        while True:
+            try:
+                with open(path) as f:
+                    pid, _, body = f.read().partition("\n")
+                if pid:                 # (no liveness check here: a rank may have posted and left; rank 0 emptied the
+                    out.append(body)    # directory before it published the unique id, and flags are posted after reading that)
+                    break
+            except (FileNotFoundError, ValueError):
+                pass
+            if time.time() > t_end:
+                out.append("rank %d never reported (timeout)" % r)
+                break
+            time.sleep(0.002)
+    return out
+
+
+def file_rendezvous_cleanup(rank, world=1, timeout=60.0):
+    """Every rank says it is done with the launch directory; rank 0 removes it once all have (nobody else waits)."""
     import os
     import shutil
+    import time
+    d = _launch_dir()
+    try:
+        open(os.path.join(d, "bye_%d" % rank), "w").close()
+    except OSError:
+        return
     if rank == 0:
-        shutil.rmtree(os.path.join("/tmp", "voxcarve_rdzv_%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"))),
-                      ignore_errors=True)
+        t_end = time.time() + timeout
+        while time.time() < t_end and not all(os.path.exists(os.path.join(d, "bye_%d" % r)) for r in range(world)):
+            time.sleep(0.002)
+        shutil.rmtree(d, ignore_errors=True)
 
 
 class ShmTransport:
@@ -202,7 +259,7 @@ class ShmTransport:
     def __init__(self, n_ranks, rank):
         import os
         self.n_ranks, self.rank = n_ranks, rank
-        self.dir = os.path.join("/dev/shm", "voxcarve_xchg_%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0")))
+        self.dir = os.path.join("/dev/shm", os.path.basename(_launch_dir()).replace("rdzv", "xchg"))
         os.makedirs(self.dir, exist_ok=True)
         self.round = 0
         self._gathered = None
