@@ -246,6 +246,8 @@ def cpu_baseline(grid, cams, masks, frames, seconds, cc, device_digest=None):
                   threads=threads, cap=1 << 22, color_cam=cc)
     per_layer = (time.perf_counter() - t0) / probe
     layers = int(max(1, min(nz, seconds / max(per_layer, 1e-9))))
+    if per_layer * nz <= 3.0 * seconds:      # the whole grid is within reach: then the baseline also CHECKS the device's records
+        layers = nz
     z0 = max(0, (nz - layers) // 2)
     t0 = time.perf_counter()
     res = carve_c.carve(nx, ny, nz, oc, masks, frames, index_range=(z0 * layer, (z0 + layers) * layer),

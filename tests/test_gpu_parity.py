@@ -789,7 +789,7 @@ def test_index_width_at_the_u32_limit(eng, cams, masks, frames):
         eng.set_grid(2048, 2048, 1024)                         # 2^32 voxels: refused
 
 
-def _run_bench(args, nproc=1, timeout=300):
+def _run_bench(args, nproc=1, timeout=300, expect_rc=None):
     """bench.py in a child process (as the driver launches it); returns the parsed JSON line of rank 0."""
     import subprocess
     import sys
