@@ -254,6 +254,50 @@ def test_hostile_cameras_inside_the_volume(eng, seed):
     assert total > 500
 
 
+def test_config5_full_size_512_cubed_16_cameras_1080p(eng):
+    """BASELINE config 5 AT FULL SIZE: 512^3 x 16 synthetic ring cameras x 1080x1920 masks with the specified 0.5 % salt
+    noise, colour on.  The C oracle carves the whole grid (2.1 G voxel-views, seconds on the GPU box's host cores) and every
+    record -- index, colour, seen flag -- of both device modes must equal it; then the 8-slab split in the compact exchange
+    form (occupancy words packed per slab, expanded on one device) must reproduce the same list."""
+    from voxcarve import slabs, synthetic
+    from oracle import carve_c
+    if len(os.sched_getaffinity(0)) < 16:
+        pytest.skip("the full-grid oracle needs a many-core host")
+    H, W, C = 1080, 1920, 16
+    scams = synthetic.ring_cameras(C, H, W)
+    smasks = synthetic.ellipsoid_masks(scams, H, W)
+    sframes = synthetic.random_frames(C, H, W)
+    grid = (512, 512, 512)
+    want = carve_c.carve(*grid, fx.oracle_cams(scams), smasks, sframes, color_cam=1, cap=1 << 24)
+    assert want["count"] > 10 ** 6
+    eng.set_grid(*grid)
+    eng.set_cameras(scams, H, W)
+    eng.upload_masks(smasks)
+    eng.upload_frame(1, sframes[1])
+    eng.build_lut()
+    digest = None
+    for mode in ("lut", "fused"):
+        for lds in (16, 64):                                  # block grids of 32 px and of 16 px
+            eng.set_option("grid_lds_kb", lds)
+            eng.touch_masks(0)
+            assert eng.carve(mode=mode, color_cam=1) == want["count"], (mode, lds)
+            rec = eng.fetch_records()
+            idx, rgb, seen = voxcarve_unpack(rec)
+            assert np.array_equal(idx, want["idx"]) and np.array_equal(rgb[:, ::-1], want["bgr"]) and seen.all(), (mode, lds)
+            digest = hashlib.sha256(rec.tobytes()).hexdigest()
+    eng.set_option("grid_lds_kb", 16)
+    eng.touch_masks(0)
+    ents = []
+    for r in range(8):
+        z0, z1 = slabs.slab_range(512, 8, r)
+        eng.set_slab(z0, z1)
+        eng.carve(mode="fused", records=False, color_cam=1)
+        ents.append(eng.pack_entries())
+    assert eng.expand_entries(slabs.merge_rank_entries(ents)) == want["count"]
+    assert hashlib.sha256(eng.fetch_gathered().tobytes()).hexdigest() == digest
+    eng.set_slab(0, 512)
+
+
 def test_config5_shape_16_cameras_1080p(eng):
     """BASELINE config 5 inputs (16 synthetic ring cameras, 1080x1920 masks, colour on) at an
     oracle-sized grid: masks too large for the LDS path, 16-bit camera bitmask, all modes."""

@@ -48,8 +48,10 @@ struct GridCam {
 constexpr uint32_t kHdrShift = 3 * kMaxCameras;        // log2 of the block edge in pixels
 constexpr uint32_t kHdrWords = kHdrShift + 1;          // u32 words of header + grids (what the hierarchical kernels stage in LDS)
 constexpr uint32_t kHdrCount = kHdrShift + 4;          // kMaxCameras pass counts of a voxel sample: the camera visiting order
-constexpr uint32_t kHdrBox = kHdrCount + kMaxCameras;  // [2][kMaxCameras][4] foreground pixel boxes, double-buffered by frame parity
-constexpr uint32_t kGridHeader = kHdrBox + 2 * kMaxCameras * 4;   // 196 words = 49 x 16 bytes
+constexpr uint32_t kGridHeader = kHdrCount + kMaxCameras;   // 68 words = 17 x 16 bytes
+// The cameras' foreground pixel boxes (k_prep_pack -> k_prep_grid) live beside the header, one 128-byte line per camera so
+// that the workgroups of different cameras do not meet on a line, double-buffered by frame parity: [2][kMaxCameras][kBoxStride].
+constexpr uint32_t kBoxStride = 32;
 __device__ __forceinline__ uint32_t hdr_u32(const uint32_t *hdr, uint32_t i)          // wave-uniform i
 {
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr[i]);
@@ -1404,28 +1406,33 @@ struct PrepParams {
     uint32_t *fdst[kMaxCameras];       // ... into BGRX
     uint32_t *bits;                    // [C][mwords]
     uint32_t *grid;                    // the frame set's header + grids
+    uint32_t *boxes;                   // [2][kMaxCameras][kBoxStride] foreground boxes
     uint32_t C, H, W, HW, mwords, nframes;
-    uint32_t parity;                   // which of the header's two box sets this frame fills
+    uint32_t parity;                   // which of the two box sets this frame fills
+    uint32_t iters;                    // 256-word chunks per packing workgroup (large frame sets: fewer workgroups meet on the boxes)
 };
 
 __global__ __launch_bounds__(kBlock) void k_prep_pack(const PrepParams p)
 {
     __shared__ uint32_t s_red[kBlock / 64][4];
-    // workgroups [0, C * pw): camera y packs 256 mask words each; then fw per image: 1024 pixels each
-    const uint32_t pw = (p.mwords + kBlock - 1) / kBlock, fw = (p.HW + 4 * kBlock - 1) / (4 * kBlock);
+    // workgroups [0, C * pw): camera y packs iters x 256 mask words each; then fw per image: 1024 pixels each
+    const uint32_t pw = (p.mwords + kBlock * p.iters - 1) / (kBlock * p.iters), fw = (p.HW + 4 * kBlock - 1) / (4 * kBlock);
     const bool packing = blockIdx.x < p.C * pw;
     const uint32_t y = packing ? blockIdx.x / pw : p.C + (blockIdx.x - p.C * pw) / fw;
-    const uint32_t t = (packing ? blockIdx.x - y * pw : (blockIdx.x - p.C * pw) - (y - p.C) * fw) * kBlock + threadIdx.x;
+    const uint32_t t0 = (packing ? (blockIdx.x - y * pw) * p.iters : (blockIdx.x - p.C * pw) - (y - p.C) * fw) * kBlock + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (blockIdx.x == 0 && threadIdx.x < kMaxCameras) {
         // the sample counts of this frame start at zero (k_prep_grid adds to them); the other parity's boxes are emptied
         p.grid[kHdrCount + threadIdx.x] = 0;
-        uint32_t *ob = p.grid + kHdrBox + ((p.parity ^ 1u) * kMaxCameras + threadIdx.x) * 4;
+        uint32_t *ob = p.boxes + ((p.parity ^ 1u) * kMaxCameras + threadIdx.x) * kBoxStride;
         ob[0] = 0xffffffffu; ob[1] = 0; ob[2] = 0xffffffffu; ob[3] = 0;
     }
     if (packing) {
         uint32_t u0 = 0xffffffffu, u1 = 0, v0 = 0xffffffffu, v1 = 0;
-        if (t < p.mwords) {
+        for (uint32_t it = 0; it < p.iters; ++it) {
+            const uint32_t t = t0 + it * kBlock;
+            if (t >= p.mwords) break;
+            uint32_t wu0 = 0xffffffffu, wu1 = 0, wv0 = 0xffffffffu, wv1 = 0;
             const uint8_t *src = p.src[y];
             const uint32_t p0 = t * 32u;
             uint32_t out = 0;
@@ -1446,16 +1453,16 @@ __global__ __launch_bounds__(kBlock) void k_prep_pack(const PrepParams p)
             p.bits[(size_t)y * p.mwords + t] = out;
             if (out) {
                 const uint32_t lo = p0 + (uint32_t)__builtin_ctz(out), hi = p0 + 31u - (uint32_t)__builtin_clz(out);
-                v0 = lo / p.W; v1 = hi / p.W;
-                if (v0 == v1) { u0 = lo - v0 * p.W; u1 = hi - v1 * p.W; }
+                wv0 = lo / p.W; wv1 = hi / p.W;
+                if (wv0 == wv1) { wu0 = lo - wv0 * p.W; wu1 = hi - wv1 * p.W; }
                 else {                                            // the word spans image rows: pixel by pixel
-                    u0 = 0xffffffffu; u1 = 0;
                     for (uint32_t bits = out; bits; bits &= bits - 1) {
                         const uint32_t o = p0 + (uint32_t)__builtin_ctz(bits);
                         const uint32_t u = o - (o / p.W) * p.W;
-                        u0 = u < u0 ? u : u0; u1 = u > u1 ? u : u1;
+                        wu0 = u < wu0 ? u : wu0; wu1 = u > wu1 ? u : wu1;
                     }
                 }
+                u0 = wu0 < u0 ? wu0 : u0; u1 = wu1 > u1 ? wu1 : u1; v0 = wv0 < v0 ? wv0 : v0; v1 = wv1 > v1 ? wv1 : v1;
             }
         }
         u0 = wave_min_u32(u0); u1 = wave_max_u32(u1); v0 = wave_min_u32(v0); v1 = wave_max_u32(v1);
@@ -1468,7 +1475,7 @@ __global__ __launch_bounds__(kBlock) void k_prep_pack(const PrepParams p)
                 v0 = s_red[k][2] < v0 ? s_red[k][2] : v0; v1 = s_red[k][3] > v1 ? s_red[k][3] : v1;
             }
             if (u0 != 0xffffffffu) {                              // boxes only ever grow: skip what would not move them
-                uint32_t *bb = p.grid + kHdrBox + (p.parity * kMaxCameras + y) * 4;
+                uint32_t *bb = p.boxes + (p.parity * kMaxCameras + y) * kBoxStride;
                 if (u0 < __hip_atomic_load(bb + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(bb + 0, u0);
                 if (u1 > __hip_atomic_load(bb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(bb + 1, u1);
                 if (v0 < __hip_atomic_load(bb + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(bb + 2, v0);
@@ -1479,6 +1486,7 @@ __global__ __launch_bounds__(kBlock) void k_prep_pack(const PrepParams p)
         // four pixels per thread: 12 bytes in as three dwords, 16 bytes out
         const uint8_t *src = p.fsrc[y - p.C];
         uint32_t *dst = p.fdst[y - p.C];
+        const uint32_t t = t0;
         const uint32_t i4 = t * 4u;
         if (i4 + 4u <= p.HW) {
             const uint32_t *s4 = reinterpret_cast<const uint32_t *>(src) + 3u * t;
@@ -1513,19 +1521,20 @@ __device__ __forceinline__ void span_any_all(const uint32_t *__restrict__ mb, ui
 
 constexpr uint32_t kEstPerThread = 4;
 
-__global__ __launch_bounds__(kBlock) void k_prep_grid(const CarveParams p, uint32_t *grid, uint32_t parity, uint32_t min_shift,
-                                                      uint32_t budget_words, uint32_t nsamples)
+__global__ __launch_bounds__(kBlock) void k_prep_grid(const CarveParams p, uint32_t *grid, const uint32_t *boxes, uint32_t parity,
+                                                      uint32_t min_shift, uint32_t budget_words, uint32_t nsamples)
 {
     const uint32_t y = blockIdx.y;
     const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     if (y < p.C) {
         // ---- the plan, by every wave for itself.  lane = candidate shift: words the grids of all cameras would take
-        const uint32_t *box = grid + kHdrBox + parity * kMaxCameras * 4;
+        const uint32_t *box = boxes + parity * kMaxCameras * kBoxStride;
         const uint32_t shift_c = lane < 15u ? lane : 14u;
         uint32_t total = kGridHeader;
         for (uint32_t c = 0; c < p.C; ++c) {
-            const uint32_t b0 = hdr_u32(box, 4 * c), b1 = hdr_u32(box, 4 * c + 1), b2 = hdr_u32(box, 4 * c + 2), b3 = hdr_u32(box, 4 * c + 3);
+            const uint32_t b0 = hdr_u32(box, kBoxStride * c), b1 = hdr_u32(box, kBoxStride * c + 1), b2 = hdr_u32(box, kBoxStride * c + 2),
+                           b3 = hdr_u32(box, kBoxStride * c + 3);
             if (b0 > b1) continue;                                // no foreground in this camera
             total += 2u * (((b1 >> shift_c) >> 5) - ((b0 >> shift_c) >> 5) + 1u) * ((b3 >> shift_c) - (b2 >> shift_c) + 1u);
         }
@@ -1535,7 +1544,7 @@ __global__ __launch_bounds__(kBlock) void k_prep_grid(const CarveParams p, uint3
         // lane = camera: its descriptor at the chosen shift, offsets by a scan over the cameras
         uint32_t w_lo = 0, v_lo = 0, cws = 0, ch = 0;
         if (lane < p.C) {
-            const uint32_t b0 = box[4 * lane], b1 = box[4 * lane + 1], b2 = box[4 * lane + 2], b3 = box[4 * lane + 3];
+            const uint32_t b0 = box[kBoxStride * lane], b1 = box[kBoxStride * lane + 1], b2 = box[kBoxStride * lane + 2], b3 = box[kBoxStride * lane + 3];
             if (b0 <= b1) {
                 w_lo = (b0 >> shift) >> 5; cws = ((b1 >> shift) >> 5) - w_lo + 1u;
                 v_lo = b2 >> shift; ch = (b3 >> shift) - v_lo + 1u;

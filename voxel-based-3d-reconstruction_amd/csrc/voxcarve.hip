@@ -101,6 +101,7 @@ struct Slot {
     bool bits_valid = false;    // bits, BGRX images and the grid plan match the staged bytes
     bool grids_valid = false;   // block grids and camera order too (they also depend on grid, slab and cameras)
     DevBuf<uint32_t> grid;      // header + cropped block grids of all cameras (hierarchical kernels stage it in LDS)
+    DevBuf<uint32_t> boxes;     // the cameras' foreground pixel boxes, two sets (see kBoxStride)
     uint32_t budget_words = 0;  // LDS budget the plan was made for (fixes the dynamic LDS size of the carve launch)
     uint32_t parity = 0;        // which of the header's two foreground-box sets the current frame filled
     bool counts_zero = false;   // the header's sample counts are zero (k_prep_pack just ran)
@@ -461,7 +462,7 @@ int slot_at(vc_ctx *ctx, uint32_t slot, Slot **out)
 
 void release_slot(Slot &s)
 {
-    release(s.bytes); release(s.bits); release(s.frames); release(s.grid);
+    release(s.bytes); release(s.bits); release(s.frames); release(s.grid); release(s.boxes);
     for (int c = 0; c < VC_MAX_CAMERAS; ++c) {
         release(s.fbytes[c]);
         if (s.h_fbytes[c]) { (void)hipHostFree(s.h_fbytes[c]); s.h_fbytes[c] = nullptr; }
@@ -488,9 +489,13 @@ int ensure_prepared(vc_ctx *ctx, Slot &s, bool want_grids, const CarveParams *cp
         if (budget < kGridHeader + 128u) budget = kGridHeader + 128u;         // room for every camera's grid at the coarsest block
         if (budget + 8 > s.grid.cap || !s.grid.ptr) {
             VC_TRY(ensure(ctx, s.grid, (size_t)budget + 8));                   // + padding: kernels copy it 16 bytes at a time
-            std::vector<uint32_t> init(s.grid.cap, 0u);                        // both box sets start empty
-            for (uint32_t k = 0; k < 2 * kMaxCameras; ++k) { init[kHdrBox + 4 * k] = 0xffffffffu; init[kHdrBox + 4 * k + 2] = 0xffffffffu; }
-            VC_HIP(ctx, hipMemcpyAsync(s.grid.ptr, init.data(), init.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+            VC_HIP(ctx, hipMemsetAsync(s.grid.ptr, 0, s.grid.cap * sizeof(uint32_t), ctx->stream));
+        }
+        if (!s.boxes.ptr) {
+            VC_TRY(ensure(ctx, s.boxes, (size_t)2 * kMaxCameras * kBoxStride));
+            std::vector<uint32_t> init(s.boxes.cap, 0u);                       // both box sets start empty
+            for (uint32_t k = 0; k < 2 * kMaxCameras; ++k) { init[kBoxStride * k] = 0xffffffffu; init[kBoxStride * k + 2] = 0xffffffffu; }
+            VC_HIP(ctx, hipMemcpyAsync(s.boxes.ptr, init.data(), init.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
             VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
             s.parity = 0;
         }
@@ -526,10 +531,14 @@ int ensure_prepared(vc_ctx *ctx, Slot &s, bool want_grids, const CarveParams *cp
             pp.nframes++;
             s.frame_dirty[c] = 0;
         }
-        pp.bits = s.bits.ptr; pp.grid = s.grid.ptr;
+        pp.bits = s.bits.ptr; pp.grid = s.grid.ptr; pp.boxes = s.boxes.ptr;
         pp.C = C; pp.H = ctx->H; pp.W = ctx->W; pp.HW = (uint32_t)HW; pp.mwords = ctx->mwords;
         pp.parity = s.parity;
-        const uint32_t pw = (ctx->mwords + kBlock - 1) / kBlock, fw = (uint32_t)((HW + 4 * kBlock - 1) / (4 * kBlock));
+        // about a thousand packing workgroups at most: every one of them looks at (and may update) its camera's box
+        const uint64_t total_words = (uint64_t)ctx->mwords * C;
+        pp.iters = (uint32_t)(total_words / (256ull * 1024ull));
+        pp.iters = pp.iters < 1 ? 1 : (pp.iters > 16 ? 16 : pp.iters);
+        const uint32_t pw = (ctx->mwords + kBlock * pp.iters - 1) / (kBlock * pp.iters), fw = (uint32_t)((HW + 4 * kBlock - 1) / (4 * kBlock));
         hipLaunchKernelGGL(k_prep_pack, dim3(C * pw + pp.nframes * fw), dim3(kBlock), 0, ctx->stream, pp);
         VC_HIP(ctx, hipGetLastError());
         s.read_pending = false;          // the caller points e_read at an event it records behind these kernels
@@ -548,7 +557,7 @@ int ensure_prepared(vc_ctx *ctx, Slot &s, bool want_grids, const CarveParams *cp
         // a camera's grids hold at most 16 blocks per budgeted word
         const uint32_t grid_wgs = (16u * s.budget_words + kBlock - 1) / kBlock;
         hipLaunchKernelGGL(k_prep_grid, dim3(grid_wgs > est_wgs ? grid_wgs : est_wgs, C + (est_wgs ? 1 : 0)), dim3(kBlock), 0, ctx->stream, p,
-                           s.grid.ptr, s.parity, (uint32_t)ctx->grid_min_shift, s.budget_words, ns);
+                           s.grid.ptr, (const uint32_t *)s.boxes.ptr, s.parity, (uint32_t)ctx->grid_min_shift, s.budget_words, ns);
         VC_HIP(ctx, hipGetLastError());
         s.grids_valid = true;
     }
