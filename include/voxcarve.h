@@ -131,7 +131,13 @@ int vc_upload_frame(vc_ctx *ctx, uint32_t slot, uint32_t cam, const uint8_t *bgr
 /* Projects this rank's slab once into int32 [C][n]: int(y)*W + int(x), or -1 when the
  * float coordinates fail the bounds test of line 110.  Needed by VC_MODE_LUT only. */
 int vc_build_lut(vc_ctx *ctx);
-int vc_fetch_lut(vc_ctx *ctx, uint32_t cam, int32_t *out);   /* n entries (tests) */
+int vc_fetch_lut(vc_ctx *ctx, uint32_t cam, int32_t *out);   /* n entries, voxel order */
+/* The way back: replaces the pickled lookup table the reference can load instead of rebuilding it (load_lookup_table,
+ * assignment.py:12-15).  One camera's n entries in voxel order, exactly what vc_fetch_lut gives out; once all cameras of
+ * the context have been handed in the table is adopted (tile order, word and brick boxes reduced from it) and VC_MODE_LUT
+ * runs on it.  Entries outside [-1, H*W) count as -1.  The host side (CarveEngine.save_lut / load_lut) wraps the table
+ * with grid, slab, bounds, mask size and a digest of the camera parameters and refuses a file that does not match. */
+int vc_upload_lut(vc_ctx *ctx, uint32_t cam, const int32_t *lut);
 /* Device projection of arbitrary points with camera cam: uv = [n,2] float64 (tests). */
 int vc_project(vc_ctx *ctx, uint32_t cam, const double *xyz, uint64_t n, double *uv);
 

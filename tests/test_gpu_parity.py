@@ -702,6 +702,65 @@ def test_set_voxel_positions_drop_in(built, cams, masks, frames):
     del src
 
 
+def test_lut_file_round_trip_and_rejection(eng, cams, masks, frames, tmp_path):
+    """SURVEY 8(f)-4 (reference: load_lookup_table, assignment.py:12-15): the packed table saved to a file and handed back to a
+    context gives the same carve without projecting again; a file made for another grid, slab or camera set is refused; a
+    table that does NOT come from this library's projection is used as it is (never silently re-projected)."""
+    from voxcarve._lib import VoxcarveError
+    from oracle import carve_c
+    path = str(tmp_path / "lut.npz")
+    for grid in ((64, 64, 64), (16, 256, 20), (9, 70, 7)):                  # tile words / brick pipeline / y-line words
+        setup_real(eng, cams, masks, frames, grid)
+        eng.build_lut()
+        want = eng.carve(mode="lut")
+        rec = eng.fetch_records()
+        tables = np.stack([eng.fetch_lut(c) for c in range(4)])
+        eng.save_lut(path)
+        eng.set_cameras(cams, *masks[0].shape)                              # forgets every table
+        with pytest.raises(VoxcarveError, match="vc_build_lut"):
+            eng.carve(mode="lut")
+        eng.load_lut(path)
+        assert eng.carve(mode="lut") == want and np.array_equal(eng.fetch_records(), rec), grid
+        assert np.array_equal(np.stack([eng.fetch_lut(c) for c in range(4)]), tables), grid
+        for opts in ({"lut_hier": 0}, {"force_generic": 1}, {"lut_tile": 0}, {"strips": 0}):   # every LUT kernel family reads the adopted table
+            for k, v in opts.items():
+                eng.set_option(k, v)
+            assert eng.carve(mode="lut") == want and np.array_equal(eng.fetch_records(), rec), (grid, opts)
+            for k in opts:
+                eng.set_option(k, {"lut_hier": 1, "force_generic": 0, "lut_tile": 1, "strips": 1}[k])
+    # a foreign table: camera 3 blind in the upper half of the slab -- the carve follows the table, not the cameras
+    grid = (16, 256, 20)
+    setup_real(eng, cams, masks, frames, grid)
+    eng.build_lut()
+    tables = np.stack([eng.fetch_lut(c) for c in range(4)])
+    full = carve_c.carve(*grid, fx.oracle_cams(cams), masks, frames)
+    half = 16 * 256 * 10
+    tables[3, half:] = -1
+    eng.upload_lut(tables)
+    assert eng.carve(mode="lut") == int((full["idx"] < half).sum())
+    assert np.array_equal(eng.fetch()[0], full["idx"][full["idx"] < half])
+    assert np.array_equal(eng.fetch_lut(3), tables[3])                      # handed back as it came in
+    # refusal: other slab, other grid, other cameras, not a table file at all
+    eng.build_lut()
+    eng.save_lut(path)
+    eng.set_slab(0, 10)
+    with pytest.raises(VoxcarveError, match="slab"):
+        eng.load_lut(path)
+    eng.set_grid(16, 256, 24)
+    with pytest.raises(VoxcarveError, match="grid"):
+        eng.load_lut(path)
+    eng.set_grid(*grid)
+    moved = list(cams)
+    from voxcarve.camera import Camera
+    moved[2] = Camera(cams[2].K, cams[2].dist, cams[2].rvec, cams[2].tvec + 1.0)
+    eng.set_cameras(moved, *masks[0].shape)
+    with pytest.raises(VoxcarveError, match="cameras_sha256"):
+        eng.load_lut(path)
+    np.savez(path, lut=np.zeros(3, np.int32))
+    with pytest.raises(Exception):
+        eng.load_lut(path)
+
+
 def test_error_paths_raise(eng, cams, masks):
     from voxcarve._lib import VoxcarveError
     eng.set_grid(8, 8, 8)

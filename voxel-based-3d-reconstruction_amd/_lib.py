@@ -61,6 +61,7 @@ SIGNATURES = {
     "vc_upload_frame": (ctypes.c_int, [c_ctx, ctypes.c_uint32, ctypes.c_uint32, c_u8p]),
     "vc_build_lut": (ctypes.c_int, [c_ctx]),
     "vc_fetch_lut": (ctypes.c_int, [c_ctx, ctypes.c_uint32, c_i32p]),
+    "vc_upload_lut": (ctypes.c_int, [c_ctx, ctypes.c_uint32, c_i32p]),
     "vc_project": (ctypes.c_int, [c_ctx, ctypes.c_uint32, c_f64p, ctypes.c_uint64, c_f64p]),
     "vc_carve": (ctypes.c_int, [c_ctx, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_int,
                                 ctypes.c_uint32, c_u64p]),

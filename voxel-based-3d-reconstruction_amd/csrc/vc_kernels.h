@@ -969,6 +969,42 @@ __global__ __launch_bounds__(kBlock) void k_build_lut(const CarveParams p, int32
     }
 }
 
+// A table handed in from outside (vc_upload_lut: y-major int32 [C][n_pad], what vc_fetch_lut gives out) is adopted into the
+// layout the kernels read.  TILE: element e of tile word T is row r = e / 16 of its row quad, y = 16 * ty + e % 16 -- the table
+// is permuted into tile order and the tile words' pixel boxes are reduced from it; else only the y-line words' boxes are.
+template <bool TILE>
+__global__ __launch_bounds__(kBlock) void k_adopt_lut(const CarveParams p, const int32_t *__restrict__ lut,
+                                                      int32_t *__restrict__ lut_tile, uint64_t *__restrict__ box)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;      // grid covers n_pad exactly
+    const uint64_t T = t >> 6;
+    const uint32_t e = (uint32_t)t & 63u, r = e >> 4, yy = e & 15u;
+    const bool valid = t < p.n;
+    uint64_t j = t;
+    if (TILE && valid) {
+        const uint32_t quad = (uint32_t)(T / p.tq), ty = (uint32_t)(T - (uint64_t)quad * p.tq);
+        const uint32_t qpl = p.nx >> 2;
+        const uint32_t izl = quad / qpl, qx = quad - izl * qpl;
+        j = ((uint64_t)izl * p.nx + qx * 4 + r) * p.ny + (uint64_t)ty * 16 + yy;
+    }
+    const uint64_t nwords = p.n_pad >> 6;
+    for (uint32_t c = 0; c < p.C; ++c) {
+        int32_t off = valid ? lut[(size_t)c * p.n_pad + j] : -1;
+        if (off >= (int32_t)(p.H * p.W)) off = -1;                        // a foreign table cannot point outside the masks
+        if (TILE) lut_tile[(size_t)c * p.n_pad + t] = off;
+        const uint32_t pv = off >= 0 ? (uint32_t)off / p.W : 0u;
+        const uint32_t pu = off >= 0 ? (uint32_t)off - pv * p.W : 0u;
+        const uint32_t u0 = wave_min_u32(off >= 0 ? pu : 0xffffu), u1 = wave_max_u32(pu);
+        const uint32_t v0 = wave_min_u32(off >= 0 ? pv : 0xffffu), v1 = wave_max_u32(pv);
+        const bool inside = __ballot(off >= 0) == ~0ull;
+        if (e == 0)
+            box[(size_t)c * nwords + T] =
+                (u0 == 0xffffu) ? kEmptyBox
+                                : ((uint64_t)u0 | ((uint64_t)v0 << 16) | ((uint64_t)u1 << 32) | ((uint64_t)v1 << 48) |
+                                   (inside ? kBoxAllInside : 0ull));
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void k_project(const CamDev cam, const double *__restrict__ xyz,
                                                     uint64_t n, double *__restrict__ uv)
 {
@@ -1839,6 +1875,14 @@ __device__ __forceinline__ uint32_t tile_index(uint32_t j, uint32_t nx, uint32_t
     uint32_t ix, iy, izl;
     decompose(j, nx, ny, ix, iy, izl);
     return (((izl * (nx >> 2) + (ix >> 2)) * tq + (iy >> 4)) << 6) + ((ix & 3u) << 4) + (iy & 15u);
+}
+
+// The y-major table back out of the tile-ordered one (a table that came in through vc_upload_lut is never re-projected).
+__global__ __launch_bounds__(kBlock) void k_untile_lut(const CarveParams p, const int32_t *__restrict__ lut_tile, int32_t *__restrict__ lut)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x;      // grid covers n_pad exactly
+    for (uint32_t c = 0; c < p.C; ++c)
+        lut[(size_t)c * p.n_pad + j] = j < p.n ? lut_tile[(size_t)c * p.n_pad + tile_index((uint32_t)j, p.nx, p.ny, p.tq)] : -1;
 }
 
 // r-th (0-based) set bit of x; requires r < popcount(x).

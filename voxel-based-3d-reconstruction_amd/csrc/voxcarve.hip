@@ -218,6 +218,8 @@ struct vc_ctx {
     int fused_color_table = 0;       // VC_MODE_FUSED: colour the survivors from the colour camera's table (one camera, whole grid)
     int fused_boxes = 1;             // ... or read from boxes reduced once from the exact pixels (no table involved)
     bool lut_valid = false;          // vc_build_lut ran for this grid / slab / cameras (tile-ordered table, or y-major where tiles do not apply)
+    uint32_t upload_mask = 0;        // cameras handed in by vc_upload_lut so far
+    bool lut_foreign = false;        // the table in use came in through vc_upload_lut
     bool ymajor_valid = false;       // the y-major table + y-line boxes exist (built on demand: streaming / generic kernels, vc_fetch_lut)
     // tuning knobs (vc_set_option); defaults are the measured best on MI355X
     bool force_generic = false;      // one-thread-per-voxel kernels only (cross-check path)
@@ -912,7 +914,7 @@ int vc_set_grid(vc_ctx *ctx, uint32_t nx, uint32_t ny, uint32_t nz, const double
     ctx->have_grid = true;
     for (Slot &sl : ctx->slots) sl.grids_valid = false;       // the camera order was sampled on the old geometry
     if (ctx->h_lists) ctx->h_lists[0] = ctx->h_lists[1] = ctx->h_lists[2] = 0xffffffffu;
-    ctx->lut_valid = false; ctx->ymajor_valid = false; ctx->tile_valid = false; ctx->bbox_valid = false; ctx->tbox_valid = false; ctx->kbox_valid = false; ctx->carved = false; ctx->gathered = false; ctx->viewmask_valid = false;
+    ctx->lut_valid = false; ctx->upload_mask = 0; ctx->ymajor_valid = false; ctx->tile_valid = false; ctx->bbox_valid = false; ctx->tbox_valid = false; ctx->kbox_valid = false; ctx->carved = false; ctx->gathered = false; ctx->viewmask_valid = false;
     ctx->lut_color_cam = -1; ctx->packed = false;
     return VC_OK;
 }
@@ -925,7 +927,7 @@ int vc_set_slab(vc_ctx *ctx, uint32_t z0, uint32_t z1)
     if (z0 > z1 || z1 > ctx->nz) return fail(ctx, VC_ERR_ARG, "slab [%u,%u) outside [0,%u]", z0, z1, ctx->nz);
     ctx->z0 = z0; ctx->z1 = z1;
     for (Slot &sl : ctx->slots) sl.grids_valid = false;
-    ctx->lut_valid = false; ctx->ymajor_valid = false; ctx->tile_valid = false; ctx->bbox_valid = false; ctx->tbox_valid = false; ctx->kbox_valid = false; ctx->carved = false; ctx->gathered = false; ctx->viewmask_valid = false;
+    ctx->lut_valid = false; ctx->upload_mask = 0; ctx->ymajor_valid = false; ctx->tile_valid = false; ctx->bbox_valid = false; ctx->tbox_valid = false; ctx->kbox_valid = false; ctx->carved = false; ctx->gathered = false; ctx->viewmask_valid = false;
     ctx->packed = false;
     return VC_OK;
 }
@@ -969,7 +971,7 @@ int vc_set_cameras(vc_ctx *ctx, uint32_t C, const double *K9, const double *dist
         for (Slot &s : ctx->slots) release_slot(s);
     }
     for (Slot &sl : ctx->slots) sl.grids_valid = false;
-    ctx->lut_valid = false; ctx->ymajor_valid = false; ctx->tile_valid = false; ctx->bbox_valid = false; ctx->tbox_valid = false; ctx->kbox_valid = false; ctx->carved = false; ctx->gathered = false; ctx->viewmask_valid = false;
+    ctx->lut_valid = false; ctx->upload_mask = 0; ctx->ymajor_valid = false; ctx->tile_valid = false; ctx->bbox_valid = false; ctx->tbox_valid = false; ctx->kbox_valid = false; ctx->carved = false; ctx->gathered = false; ctx->viewmask_valid = false;
     ctx->lut_color_cam = -1; ctx->packed = false;
     return VC_OK;
 }
@@ -1082,7 +1084,12 @@ static int ensure_ymajor(vc_ctx *ctx)
     if (n) {
         CarveParams p;
         fill_params(ctx, p);
-        hipLaunchKernelGGL(k_build_lut<false>, dim3(grid_for(n_pad)), dim3(kBlock), 0, ctx->stream, p, ctx->d_lut.ptr, ctx->d_bbox.ptr);
+        if (ctx->lut_foreign && ctx->tile_valid) {               // a table that was handed in: permuted back, never re-projected
+            hipLaunchKernelGGL(k_untile_lut, dim3(grid_for(n_pad)), dim3(kBlock), 0, ctx->stream, p, (const int32_t *)ctx->d_lut_tile.ptr, ctx->d_lut.ptr);
+            hipLaunchKernelGGL(k_adopt_lut<false>, dim3(grid_for(n_pad)), dim3(kBlock), 0, ctx->stream, p, (const int32_t *)ctx->d_lut.ptr,
+                               (int32_t *)nullptr, ctx->d_bbox.ptr);
+        }
+        else hipLaunchKernelGGL(k_build_lut<false>, dim3(grid_for(n_pad)), dim3(kBlock), 0, ctx->stream, p, ctx->d_lut.ptr, ctx->d_bbox.ptr);
         VC_HIP(ctx, hipGetLastError());
     }
     ctx->bbox_valid = true;
@@ -1100,6 +1107,7 @@ int vc_build_lut(vc_ctx *ctx)
     const uint64_t n_pad = (n + kLutPad - 1) / kLutPad * kLutPad;
     VC_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     ctx->tile_valid = false;
+    ctx->lut_foreign = false; ctx->ymajor_valid = false; ctx->upload_mask = 0;
     if (ctx->lut_tile && ctx->nx % 4 == 0 && ctx->ny % 64 == 0) {
         // ONE table, in tile order (words of 4 x-rows x 16 y), projected straight into that order; the colour look-up of
         // the record expansion reads it too (closed-form index).  No y-major copy unless something asks for one.
@@ -1121,6 +1129,60 @@ int vc_build_lut(vc_ctx *ctx)
     VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.lut_ms, ctx->ev[0], ctx->ev[1]));
     ctx->lut_valid = true;
+    ctx->lut_foreign = false;
+    return VC_OK;
+}
+
+// One camera's table from the host (the counterpart of vc_fetch_lut; reference: the pickled lookup table that
+// assignment.py:12-15 loads).  When every camera has been handed in, the tables are adopted: permuted into tile order
+// where the grid allows (the y-major copy is released again) and the word / brick boxes are reduced from them.
+int vc_upload_lut(vc_ctx *ctx, uint32_t cam, const int32_t *lut)
+{
+    if (!ctx || !lut) return VC_ERR_ARG;
+    if (ctx->npending) return fail(ctx, VC_ERR_ARG, "carve steps are in flight: collect them with vc_carve_end first");
+    if (!ctx->have_grid || !ctx->have_cams) return fail(ctx, VC_ERR_ARG, "grid and cameras must be set before vc_upload_lut");
+    if (cam >= ctx->C) return fail(ctx, VC_ERR_ARG, "camera %u not in [0,%u)", cam, ctx->C);
+    VC_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t n = ctx->n_voxels();
+    const uint64_t n_pad = (n + kLutPad - 1) / kLutPad * kLutPad;
+    if (ctx->upload_mask == 0) {                                 // first camera of a new table: whatever was there is void
+        ctx->lut_valid = false; ctx->ymajor_valid = false; ctx->tile_valid = false; ctx->bbox_valid = false; ctx->tbox_valid = false; ctx->kbox_valid = false;
+        VC_TRY(ensure(ctx, ctx->d_lut, (size_t)n_pad * ctx->C));
+        VC_HIP(ctx, hipMemsetAsync(ctx->d_lut.ptr, 0xff, (size_t)n_pad * ctx->C * sizeof(int32_t), ctx->stream));   // padding = -1
+    }
+    if (n) VC_HIP(ctx, hipMemcpyAsync(ctx->d_lut.ptr + (size_t)cam * n_pad, lut, n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->upload_mask |= 1u << cam;
+    if (ctx->upload_mask != (ctx->C >= 32 ? 0xffffffffu : (1u << ctx->C) - 1u)) return VC_OK;
+    ctx->upload_mask = 0;
+    CarveParams p;
+    fill_params(ctx, p);
+    if (ctx->lut_tile && ctx->nx % 4 == 0 && ctx->ny % 64 == 0) {
+        VC_TRY(ensure(ctx, ctx->d_lut_tile, (size_t)n_pad * ctx->C));
+        VC_TRY(ensure(ctx, ctx->d_tbox, (size_t)(n_pad / 64) * ctx->C));
+        if (n) {
+            hipLaunchKernelGGL(k_adopt_lut<true>, dim3(grid_for(n_pad)), dim3(kBlock), 0, ctx->stream, p, (const int32_t *)ctx->d_lut.ptr,
+                               ctx->d_lut_tile.ptr, ctx->d_tbox.ptr);
+            VC_HIP(ctx, hipGetLastError());
+            ctx->tile_valid = true;
+            ctx->tbox_valid = true;
+            VC_TRY(build_brick_boxes(ctx));
+        }
+        VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        release(ctx->d_lut);                                     // one table, as after vc_build_lut
+    } else {
+        VC_TRY(ensure(ctx, ctx->d_bbox, (size_t)(n_pad / 64) * ctx->C));
+        if (n) {
+            hipLaunchKernelGGL(k_adopt_lut<false>, dim3(grid_for(n_pad)), dim3(kBlock), 0, ctx->stream, p, (const int32_t *)ctx->d_lut.ptr,
+                               (int32_t *)nullptr, ctx->d_bbox.ptr);
+            VC_HIP(ctx, hipGetLastError());
+        }
+        VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->bbox_valid = true;
+        ctx->ymajor_valid = true;
+    }
+    ctx->lut_valid = true;
+    ctx->lut_foreign = true;
     return VC_OK;
 }
 

@@ -97,6 +97,7 @@ class CarveEngine:
         self._check(self._L.vc_set_cameras(self._ctx, len(cams), _ptr(K9, dp), _ptr(d5, dp), _ptr(R9, dp),
                                            _ptr(t3, dp), H, W), "vc_set_cameras")
         self.n_cameras = len(cams)
+        self._cams = cams
         self.image_size = (int(H), int(W))
 
     # -- per-frame inputs -----------------------------------------------------------
@@ -144,6 +145,48 @@ class CarveEngine:
         out = np.empty(self.n_voxels, dtype=np.int32)
         self._check(self._L.vc_fetch_lut(self._ctx, cam, _ptr(out, ctypes.c_int32)), "vc_fetch_lut")
         return out
+
+    # -- lookup-table persistence (reference: the pickled table of assignment.py:12-15; here a .npz, nothing executable) ----
+    def _lut_meta(self):
+        import hashlib
+        h = hashlib.sha256()
+        for c in self._cams:
+            for a in (c.K, c.dist, c.R, c.tvec):
+                h.update(np.ascontiguousarray(a, dtype=np.float64).tobytes())
+        return {"format": "voxcarve-lut-1", "grid": list(self.grid), "slab": list(self.slab), "bounds": list(self.bounds),
+                "image_size": list(self.image_size), "cameras": self.n_cameras, "cameras_sha256": h.hexdigest(),
+                "entry": "int32 pixel offset int(v) * W + int(u) of the voxel's projection, -1 outside the image "
+                         "(voxel_reconstruction.py:110-112); voxel order i = iz*nx*ny + ix*ny + iy of the slab"}
+
+    def save_lut(self, path):
+        """Writes the packed table of this context (grid, slab, cameras) as <path> (.npz: 'lut' int32 [C, n] + 'meta' JSON)."""
+        import json
+        lut = np.stack([self.fetch_lut(c) for c in range(self.n_cameras)])
+        with open(path, "wb") as f:
+            np.savez(f, lut=lut, meta=np.frombuffer(json.dumps(self._lut_meta()).encode(), dtype=np.uint8))
+
+    def load_lut(self, path):
+        """Hands a table written by save_lut to the device instead of projecting it again.  The file must have been made
+        for exactly this grid, slab, bounds, mask size and these cameras: anything else raises VoxcarveError."""
+        import json
+        with np.load(path, allow_pickle=False) as z:
+            meta = json.loads(bytes(z["meta"]).decode())
+            want = self._lut_meta()
+            bad = [k for k in want if k != "entry" and meta.get(k) != want[k]]
+            if bad:
+                raise _lib.VoxcarveError("lookup table %s was made for another configuration (differs in: %s)" % (path, ", ".join(bad)))
+            lut = z["lut"]
+            if lut.dtype != np.int32 or lut.shape != (self.n_cameras, self.n_voxels):
+                raise _lib.VoxcarveError("lookup table %s: array %s %s, expected int32 %s" % (path, lut.dtype, lut.shape, (self.n_cameras, self.n_voxels)))
+            self.upload_lut(lut)
+
+    def upload_lut(self, lut):
+        """int32 [C, n] in voxel order (what fetch_lut gives out per camera); adopted once all cameras are in."""
+        lut = np.ascontiguousarray(lut, dtype=np.int32)
+        if lut.shape != (self.n_cameras, self.n_voxels):
+            raise ValueError("lut shape %s, expected %s" % (lut.shape, (self.n_cameras, self.n_voxels)))
+        for c in range(self.n_cameras):
+            self._check(self._L.vc_upload_lut(self._ctx, c, _ptr(lut[c], ctypes.c_int32)), "vc_upload_lut")
 
     def project(self, cam, points):
         p = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
