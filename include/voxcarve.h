@@ -172,6 +172,20 @@ int vc_fetch_viewmask(vc_ctx *ctx, uint16_t *viewmask);
  * slab-local voxel j (consumer shape of assignment.py:143-146). */
 int vc_fetch_occupancy(vc_ctx *ctx, uint8_t *bits);
 
+/* ---- the step after the path: marching cubes over the dense ON/OFF volume -------------------------------
+ * Replaces skimage.measure.marching_cubes(voxels_status, 0) of plot_marching_cubes, voxel_reconstruction.py:127-163, whose
+ * input the reference builds as the statuses in voxel order reshaped to (width, height*2, depth) (assignment.py:143-146).
+ * volume_bits: d0*d1*d2 bits, element i = bit (i & 7) of byte i >> 3, C order (axis 2 fastest); NULL = the occupancy of
+ * the last carve of this context, viewed as a (d0, d1, d2) array over the voxel index (d0*d1*d2 must equal the slab's
+ * voxel count: (nx, ny, nz) is literally the reference's reshape, (nz, nx, ny) the geometric axes).  Vertices lie on the
+ * cube edges between an ON and an OFF element at off + level * (on - off), 0 <= level < 1 (the reference passes 0), in
+ * index coordinates (axis 0, 1, 2); faces index them, oriented from ON to OFF.  Classic table-driven marching cubes; the
+ * table is generated (csrc/mc_table.h), NOT scikit-image's Lewiner variant: parity with skimage is unpinned. */
+int vc_marching_cubes(vc_ctx *ctx, const uint8_t *volume_bits, uint32_t d0, uint32_t d1, uint32_t d2, float level,
+                      uint64_t *n_verts, uint64_t *n_faces);
+/* verts: float [n_verts][3], faces: u32 [n_faces][3] of the last vc_marching_cubes; either may be NULL. */
+int vc_fetch_mesh(vc_ctx *ctx, float *verts, uint32_t *faces);
+
 /* Tuning knobs: which of the equivalent kernels runs and with what launch geometry; NEVER changes results
  * (tests/test_gpu_parity.py runs every family against the oracle).  Defaults are the measured best on MI355X.
  *   kernel choice   lut_hier (1)  hierarchical lookup-table kernel, 0 = stream the table (k_lut_first + refine)

@@ -761,6 +761,54 @@ def test_lut_file_round_trip_and_rejection(eng, cams, masks, frames, tmp_path):
         eng.load_lut(path)
 
 
+def test_marching_cubes_on_device_equals_restatement(eng, cams, masks, frames):
+    """the HIP marching cubes against oracle/marching_np.extract, vertex for vertex and face for face: volumes
+    whose size is no multiple of 64 (words straddle rows and slabs), degenerate shapes, noise (every ambiguous case), both
+    levels; then on the carve result itself in the reference's reshape and on the geometric axes; at 256^3 by invariants."""
+    from oracle import marching_np as mc
+    rng = np.random.default_rng(5)
+    vols = [rng.random((5, 7, 9)) < 0.5, rng.random((2, 2, 2)) < 0.5, np.ones((1, 1, 1), bool), rng.random((1, 70, 3)) < 0.5,
+            rng.random((3, 1, 130)) < 0.4, np.pad(rng.random((10, 20, 30)) < 0.5, 1), rng.random((4, 64, 64)) < 0.3,
+            np.zeros((6, 6, 6), bool), np.ones((5, 5, 5), bool)]
+    for vol in vols:
+        for level in (0.0, 0.5):
+            v, f = eng.marching_cubes(vol, level=level)
+            wv, wf = mc.extract(vol, level)
+            assert v.shape == wv.shape and np.array_equal(v, wv), (vol.shape, level)
+            assert f.shape == wf.shape and np.array_equal(f, wf), (vol.shape, level)
+    # the carve's own occupancy, no volume passed in
+    setup_real(eng, cams, masks, frames, (64, 64, 64))
+    for mode in ("fused",):
+        eng.carve(mode=mode)
+        occ = eng.fetch_occupancy()
+        for axes, shape in (("reference", (64, 64, 64)), ("grid", (64, 64, 64))):
+            v, f = eng.marching_cubes(level=0.0, axes=axes)
+            wv, wf = mc.extract(occ.reshape(shape), 0.0)
+            assert np.array_equal(v, wv) and np.array_equal(f, wf), axes
+    setup_real(eng, cams, masks, frames, (32, 64, 16))
+    eng.carve(mode="fused")
+    occ = eng.fetch_occupancy()
+    for axes, shape in (("reference", (32, 64, 16)), ("grid", (16, 32, 64))):
+        v, f = eng.marching_cubes(level=0.5, axes=axes)
+        wv, wf = mc.extract(occ.reshape(shape), 0.5)
+        assert np.array_equal(v, wv) and np.array_equal(f, wf), axes
+    # config 2 size: a closed, consistently oriented surface around the hull (its cells at the volume border are cut open)
+    setup_real(eng, cams, masks, frames, (256, 256, 256))
+    eng.build_lut()
+    n = eng.carve(mode="lut")
+    v, f = eng.marching_cubes(level=0.5, axes="grid")
+    assert f.shape[0] > 100000
+    occ = eng.fetch_occupancy().reshape(256, 256, 256)
+    touches_border = occ[0].any() or occ[-1].any() or occ[:, 0].any() or occ[:, -1].any() or occ[:, :, 0].any() or occ[:, :, -1].any()
+    closed, oriented, chi, volume = mc.mesh_invariants(v, f)
+    assert oriented and (closed or touches_border)
+    if closed:
+        assert abs(volume - n) < 0.05 * n
+    from voxcarve._lib import VoxcarveError
+    with pytest.raises(VoxcarveError, match="level"):
+        eng.marching_cubes(np.ones((2, 2, 2), bool), level=1.0)
+
+
 def test_error_paths_raise(eng, cams, masks):
     from voxcarve._lib import VoxcarveError
     eng.set_grid(8, 8, 8)

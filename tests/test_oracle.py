@@ -187,3 +187,43 @@ def test_postfilter_restatement_small_cases():
     assert np.array_equal(pf.erode2x2(edge)[0], [255, 255, 255, 255])
     m = fx.golden_masks()[0]
     assert np.array_equal(pf.post_filter(m), m)              # no flags: only the binarisation
+
+
+def test_marching_cubes_table_is_the_derived_one_and_sound():
+    """SURVEY 8(f)-3.  The case table the HIP kernels include (csrc/mc_table.h, generated) equals the derivation in
+    oracle/marching_np.py, and that table is sound: on spheres, a torus, a single voxel and noise (every ambiguous case) the
+    mesh is closed, every edge is walked once in each direction (consistent ON -> OFF orientation), the Euler characteristic is
+    that of the shape and the enclosed volume is positive and close to the voxel count.  Parity with scikit-image's Lewiner
+    variant is UNPINNED (not importable here; the reference holds no mesh)."""
+    import re
+    from oracle import marching_np as mc
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    txt = open(os.path.join(root, "voxel-based-3d-reconstruction_amd", "csrc", "mc_table.h")).read()
+    ntri = [int(v) for v in re.search(r"kMcNtri\[256\] = \{([^}]*)\}", txt).group(1).split(",")]
+    rows = re.findall(r"^    \{([^}]*)\},$", txt, re.M)
+    assert ntri == [int(v) for v in mc.NTRI] and len(rows) == 256
+    for c, row in enumerate(rows):
+        assert [int(v) for v in row.split(",")][:15] == [int(v) for v in mc.TRI[c]], c
+
+    def ball(n, r):
+        g = np.indices((n, n, n)).astype(float) - (n - 1) / 2
+        return (g ** 2).sum(0) <= r * r
+    for vol, chi in ((ball(16, 5.3), 2), (ball(11, 3.0), 2)):
+        for level in (0.5, 0.0):
+            v, f = mc.extract(vol, level)
+            closed, oriented, x, volume = mc.mesh_invariants(v, f)
+            assert closed and oriented and x == chi and volume > 0
+            if level == 0.5:
+                assert abs(volume - vol.sum()) < 0.1 * vol.sum()
+                assert np.all(np.isin((v * 2) % 2, (0, 1))) and np.all(((v * 2) % 2).sum(1) == 1)   # midpoints of grid edges
+    n = 24
+    g = np.indices((n, n, n)).astype(float) - (n - 1) / 2
+    torus = ((np.sqrt(g[0] ** 2 + g[1] ** 2) - 7) ** 2 + g[2] ** 2) <= 3.2 ** 2
+    assert mc.mesh_invariants(*mc.extract(torus, 0.5))[:3] == (True, True, 0)
+    one = np.zeros((3, 3, 3), bool)
+    one[1, 1, 1] = True
+    v, f = mc.extract(one, 0.5)
+    assert f.shape[0] == 8 and mc.mesh_invariants(v, f) == (True, True, 2, 1 / 6)          # an octahedron around the voxel
+    rng = np.random.default_rng(0)
+    noise = np.pad(rng.random((7, 8, 9)) < 0.5, 1)
+    assert mc.mesh_invariants(*mc.extract(noise, 0.5))[:2] == (True, True)

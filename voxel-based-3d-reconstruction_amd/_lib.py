@@ -73,6 +73,8 @@ SIGNATURES = {
     "vc_host_free": (ctypes.c_int, [c_ctx, ctypes.c_void_p]),
     "vc_fetch_viewmask": (ctypes.c_int, [c_ctx, c_u16p]),
     "vc_fetch_occupancy": (ctypes.c_int, [c_ctx, c_u8p]),
+    "vc_marching_cubes": (ctypes.c_int, [c_ctx, c_u8p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_float, c_u64p, c_u64p]),
+    "vc_fetch_mesh": (ctypes.c_int, [c_ctx, ctypes.POINTER(ctypes.c_float), c_u32p]),
     "vc_set_option": (ctypes.c_int, [c_ctx, ctypes.c_char_p, ctypes.c_int]),
     "vc_timing": (ctypes.c_int, [c_ctx, ctypes.POINTER(VcTiming)]),
     "vc_debug_counters": (ctypes.c_int, [c_ctx, c_u64p]),

@@ -30,6 +30,7 @@
 
 #include "../../include/voxcarve.h"
 #include "vc_kernels.h"
+#include "vc_mc.h"
 
 #pragma clang fp contract(off)
 
@@ -203,6 +204,13 @@ struct vc_ctx {
     DevBuf<uint64_t> d_wlist;        // undecided words (worst case: every word of the slab)
     uint32_t *h_lists = nullptr;     // pinned [4]: list lengths of an earlier step, to size launches by
     DevBuf<uint64_t> d_trace;        // experiments (dbg & 32)
+    // marching cubes (vc_marching_cubes)
+    DevBuf<uint64_t> d_mcbits, d_mcx;
+    DevBuf<uint32_t> d_mcwbase, d_mcgv, d_mcgt, d_mcgvoff, d_mcgtoff, d_mcfaces;
+    DevBuf<uint64_t> d_mcbv, d_mcbvoff, d_mcbt, d_mcbtoff;
+    DevBuf<float> d_mcverts;
+    uint64_t mc_verts = 0, mc_faces = 0;
+    bool mc_valid = false;
     uint32_t list_parity = 0;
     int strips = 1;                  // carve by bricks where the grid shape allows (ny in {256, 512, 1024}); (option name kept)
     int dbg = 0;
@@ -852,6 +860,9 @@ int vc_destroy(vc_ctx *ctx)
     }
     for (int k = 0; k < 2; ++k) if (ctx->ev_h[k]) (void)hipEventDestroy(ctx->ev_h[k]);
     release(ctx->d_axes); release(ctx->d_morph); release(ctx->d_lut); release(ctx->d_bbox); release(ctx->d_lut_tile); release(ctx->d_tbox); release(ctx->d_kbox); release(ctx->d_live); release(ctx->d_wbox); release(ctx->d_bm); release(ctx->d_blist); release(ctx->d_wlist); release(ctx->d_trace);
+    release(ctx->d_mcbits); release(ctx->d_mcx); release(ctx->d_mcwbase); release(ctx->d_mcgv); release(ctx->d_mcgt); release(ctx->d_mcgvoff);
+    release(ctx->d_mcgtoff); release(ctx->d_mcfaces); release(ctx->d_mcbv); release(ctx->d_mcbvoff); release(ctx->d_mcbt); release(ctx->d_mcbtoff);
+    release(ctx->d_mcverts);
     for (StepBuf &b : ctx->sb) {
         release(b.words); release(b.groupcnt); release(b.groupoff); release(b.blocksum); release(b.blockoff); release(b.records);
         release(b.ent); release(b.mine); release(b.counts);
@@ -1646,6 +1657,83 @@ int vc_fetch_occupancy(vc_ctx *ctx, uint8_t *bits)
         cur.sparse_words = false;
     }
     if (nwords) VC_HIP(ctx, hipMemcpy(bits, cur.words.ptr, nwords * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return VC_OK;
+}
+
+// ---- marching cubes over the dense ON/OFF volume (reference consumer voxel_reconstruction.py:127-163) ----
+int vc_marching_cubes(vc_ctx *ctx, const uint8_t *volume_bits, uint32_t d0, uint32_t d1, uint32_t d2, float level,
+                      uint64_t *n_verts, uint64_t *n_faces)
+{
+    if (!ctx || !n_verts || !n_faces) return VC_ERR_ARG;
+    *n_verts = *n_faces = 0;
+    ctx->mc_valid = false;
+    if (d0 == 0 || d1 == 0 || d2 == 0) return fail(ctx, VC_ERR_ARG, "volume dimensions must be >= 1");
+    if (!(level >= 0.0f && level < 1.0f)) return fail(ctx, VC_ERR_ARG, "level %g not in [0, 1): ON is 1, OFF is 0", (double)level);
+    const uint64_t n = (uint64_t)d0 * d1 * d2;
+    if (n > 0xffffffffull) return fail(ctx, VC_ERR_ARG, "volume of %llu elements exceeds the u32 index", (unsigned long long)n);
+    if (ctx->npending) return fail(ctx, VC_ERR_ARG, "carve steps are in flight: collect them with vc_carve_end first");
+    VC_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t nwords = (uint32_t)((n + 63) / 64), ngroups = (nwords + 63) / 64;
+    const uint32_t nscan = (ngroups + kScanBlock - 1) / kScanBlock;
+    McParams p;
+    memset(&p, 0, sizeof p);
+    if (volume_bits) {
+        VC_TRY(ensure(ctx, ctx->d_mcbits, (size_t)nwords));
+        VC_HIP(ctx, hipMemsetAsync(ctx->d_mcbits.ptr, 0, (size_t)nwords * sizeof(uint64_t), ctx->stream));
+        VC_HIP(ctx, hipMemcpyAsync(ctx->d_mcbits.ptr, volume_bits, (size_t)((n + 7) / 8), hipMemcpyHostToDevice, ctx->stream));
+        p.bits = ctx->d_mcbits.ptr;
+    } else {
+        if (!ctx->carved) return fail(ctx, VC_ERR_ARG, "no carve result: run vc_carve first or pass a volume");
+        if (n != ctx->n_voxels()) return fail(ctx, VC_ERR_ARG, "%u x %u x %u is not the %llu voxels of the carved slab", d0, d1, d2,
+                                              (unsigned long long)ctx->n_voxels());
+        StepBuf &cur = ctx->sb[ctx->cur];
+        if (cur.sparse_words) {                  // the hierarchical kernels skip the words of groups without survivors
+            const uint32_t cg = (uint32_t)((nwords + kGroupWords - 1) / kGroupWords);
+            hipLaunchKernelGGL(k_zero_dead_groups, dim3((cg + 3) / 4), dim3(kBlock), 0, ctx->stream, cur.words.ptr, (uint64_t)nwords, cg, cur.groupcnt.ptr);
+            VC_HIP(ctx, hipGetLastError());
+            cur.sparse_words = false;
+        }
+        p.bits = cur.words.ptr;
+    }
+    VC_TRY(ensure(ctx, ctx->d_mcx, (size_t)nwords * 3));
+    VC_TRY(ensure(ctx, ctx->d_mcwbase, (size_t)nwords));
+    VC_TRY(ensure(ctx, ctx->d_mcgv, ngroups)); VC_TRY(ensure(ctx, ctx->d_mcgt, ngroups));
+    VC_TRY(ensure(ctx, ctx->d_mcgvoff, ngroups)); VC_TRY(ensure(ctx, ctx->d_mcgtoff, ngroups));
+    VC_TRY(ensure(ctx, ctx->d_mcbv, kMaxScanBlocks)); VC_TRY(ensure(ctx, ctx->d_mcbt, kMaxScanBlocks));
+    VC_TRY(ensure(ctx, ctx->d_mcbvoff, kMaxScanBlocks + 1)); VC_TRY(ensure(ctx, ctx->d_mcbtoff, kMaxScanBlocks + 1));
+    VC_TRY(ensure_exchange_scratch(ctx, 1));
+    p.n = n; p.d0 = d0; p.d1 = d1; p.d2 = d2; p.nwords = nwords; p.ngroups = ngroups;
+    p.x = ctx->d_mcx.ptr; p.wbase = ctx->d_mcwbase.ptr; p.gv = ctx->d_mcgv.ptr; p.gt = ctx->d_mcgt.ptr;
+    p.gvoff = ctx->d_mcgvoff.ptr; p.gtoff = ctx->d_mcgtoff.ptr; p.bvoff = ctx->d_mcbvoff.ptr; p.btoff = ctx->d_mcbtoff.ptr;
+    p.level = level;
+    const dim3 grid((ngroups + 3) / 4), block(kBlock);
+    hipLaunchKernelGGL(k_mc_count, grid, block, 0, ctx->stream, p);
+    VC_HIP(ctx, hipGetLastError());
+    VC_TRY(scan_counts(ctx, ctx->stream, ctx->d_mcgv.ptr, ngroups, ctx->d_mcgvoff.ptr, ctx->d_mcbv.ptr, ctx->d_mcbvoff.ptr, ctx->h_xtotal));
+    VC_TRY(scan_counts(ctx, ctx->stream, ctx->d_mcgt.ptr, ngroups, ctx->d_mcgtoff.ptr, ctx->d_mcbt.ptr, ctx->d_mcbtoff.ptr, ctx->h_xtotal + 1));
+    VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)nscan;
+    const uint64_t V = ctx->h_xtotal[0], F = ctx->h_xtotal[1];
+    if (V > 0xffffffffull) return fail(ctx, VC_ERR_ARG, "%llu vertices exceed the u32 vertex number", (unsigned long long)V);
+    VC_TRY(ensure(ctx, ctx->d_mcverts, (size_t)(3 * V + 3)));
+    VC_TRY(ensure(ctx, ctx->d_mcfaces, (size_t)(3 * F + 3)));
+    p.verts = ctx->d_mcverts.ptr; p.faces = ctx->d_mcfaces.ptr; p.vcap = V; p.fcap = F;
+    hipLaunchKernelGGL(k_mc_verts, grid, block, 0, ctx->stream, p);
+    hipLaunchKernelGGL(k_mc_faces, grid, block, 0, ctx->stream, p);
+    VC_HIP(ctx, hipGetLastError());
+    VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->mc_verts = V; ctx->mc_faces = F; ctx->mc_valid = true;
+    *n_verts = V; *n_faces = F;
+    return VC_OK;
+}
+
+int vc_fetch_mesh(vc_ctx *ctx, float *verts, uint32_t *faces)
+{
+    if (!ctx) return VC_ERR_ARG;
+    if (!ctx->mc_valid) return fail(ctx, VC_ERR_ARG, "no mesh: call vc_marching_cubes");
+    VC_HIP(ctx, hipSetDevice(ctx->device));
+    if (verts && ctx->mc_verts) VC_HIP(ctx, hipMemcpy(verts, ctx->d_mcverts.ptr, ctx->mc_verts * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (faces && ctx->mc_faces) VC_HIP(ctx, hipMemcpy(faces, ctx->d_mcfaces.ptr, ctx->mc_faces * 3 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return VC_OK;
 }
 

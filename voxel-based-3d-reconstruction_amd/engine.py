@@ -269,6 +269,31 @@ class CarveEngine:
         self._check(self._L.vc_fetch_occupancy(self._ctx, _ptr(raw, ctypes.c_uint8)), "vc_fetch_occupancy")
         return np.unpackbits(raw, bitorder="little")[:n].astype(bool)
 
+    def marching_cubes(self, volume=None, level=0.0, axes="reference"):
+        """Triangle mesh of an ON/OFF volume on the device -> (verts float32 [V, 3], faces uint32 [F, 3]).
+        volume: 3-D boolean array (what the reference hands to skimage.measure.marching_cubes, voxel_reconstruction.py:141);
+        None = the occupancy of the last carve, reshaped as the reference does it (axes="reference": (nx, ny, nz) over the
+        voxel order, assignment.py:144) or on its geometric axes (axes="grid": (nz, nx, ny), i.e. vertex = (iz, ix, iy))."""
+        nv, nf = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        if volume is None:
+            nx, ny, _ = self.grid
+            nzl = self.slab[1] - self.slab[0]
+            dims = (nx, ny, nzl) if axes == "reference" else (nzl, nx, ny)
+            bits = None
+        else:
+            vol = np.ascontiguousarray(volume).astype(bool)
+            if vol.ndim != 3:
+                raise ValueError("volume must be 3-D")
+            dims = vol.shape
+            packed = np.packbits(vol.reshape(-1), bitorder="little")
+            bits = _ptr(packed, ctypes.c_uint8)
+        self._check(self._L.vc_marching_cubes(self._ctx, bits, dims[0], dims[1], dims[2], float(level), ctypes.byref(nv), ctypes.byref(nf)),
+                    "vc_marching_cubes")
+        verts = np.empty((int(nv.value), 3), dtype=np.float32)
+        faces = np.empty((int(nf.value), 3), dtype=np.uint32)
+        self._check(self._L.vc_fetch_mesh(self._ctx, _ptr(verts, ctypes.c_float), _ptr(faces, ctypes.c_uint32)), "vc_fetch_mesh")
+        return verts, faces
+
     def set_option(self, name, value):
         """Launch-geometry tuning knobs (never change results); see vc_set_option."""
         self._check(self._L.vc_set_option(self._ctx, name.encode(), int(value)), "vc_set_option")

@@ -6,7 +6,7 @@ unchanged.  The point array and the lookup table become light handles (the refer
 only passes them back in); the visibility dictionaries are real dicts, materialised from
 the GPU's per-voxel camera bitmask ("compat" surface -- sized for the reference's 128^3;
 use ``voxcarve.engine.CarveEngine`` / ``voxcarve.assignment`` for large grids).
-``plot_marching_cubes`` (reference :127-163, dead code there) is not provided.
+``plot_marching_cubes`` (reference :127-163) runs the marching cubes on the device instead of in scikit-image.
 """
 import os
 
@@ -129,3 +129,40 @@ def update_visible_voxels_and_extract_colors(lookup_table, fg_masks, images):
             views[cam_key] = True
             voxels_visible_colors[voxel][cam_key] = np.array(bgr[k])
     return voxels_visible, voxels_visible_colors
+
+
+def marching_cubes(voxels_status, level=0, device=0):
+    """(verts float32 [V, 3], faces uint32 [F, 3]) of a 3-D ON/OFF array: the device's counterpart of the
+    ``measure.marching_cubes(voxels_status, 0)`` call of reference :141 (classic table-driven marching cubes; vertex
+    coordinates in array-index space like skimage's; parity with skimage's Lewiner variant is unpinned)."""
+    with CarveEngine(device) as eng:
+        return eng.marching_cubes(np.asarray(voxels_status), level=level)
+
+
+def plot_marching_cubes(voxels_status, rotate=True, plot_output_path="plots", plot_output_filename="marching_cubes.png"):
+    """Runs marching cubes on activated voxels and plots the result; reference :127-163, same parameters.
+
+    The mesh comes from the GPU (``marching_cubes`` above); the figure is drawn as the reference draws it."""
+    if rotate:
+        voxels_status = np.rot90(voxels_status, 2)                   # reference :138-139
+    verts, faces = marching_cubes(voxels_status, 0)
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+    from mpl_toolkits.mplot3d.art3d import Poly3DCollection
+    fig = plt.figure(figsize=(10, 10))
+    ax = fig.add_subplot(111, projection="3d")
+    mesh = Poly3DCollection(verts[faces.astype(np.int64)])
+    mesh.set_edgecolor("k")
+    ax.add_collection3d(mesh)
+    ax.set_xlabel("X")
+    ax.set_ylabel("Y")
+    ax.set_zlabel("z-axis")
+    ax.set_xlim(0, voxels_status.shape[2])
+    ax.set_ylim(0, voxels_status.shape[1])
+    ax.set_zlim(0, voxels_status.shape[0])
+    plt.tight_layout()
+    os.makedirs(plot_output_path, exist_ok=True)
+    plt.savefig(os.path.join(plot_output_path, plot_output_filename))
+    plt.close(fig)
+    return verts, faces
