@@ -190,7 +190,10 @@ int vc_fetch_mesh(vc_ctx *ctx, float *verts, uint32_t *faces);
  * (tests/test_gpu_parity.py runs every family against the oracle).  Defaults are the measured best on MI355X.
  *   kernel choice   lut_hier (1)  hierarchical lookup-table kernel, 0 = stream the table (k_lut_first + refine)
  *                   lut_tile, fused_tile (1)  words of 4 x-rows x 16 y where nx % 4 == 0 and ny % 64 == 0
- *                   cull (1)  those kernels first decide whole 16 x 16 x 16-voxel bricks from the bricks' pixel boxes (k_cull)
+ *                   bricks (1)  ny in {256, 512, 1024}: the brick pipeline (whole 16^3-voxel bricks decided from their pixel
+ *                                  boxes, flat lists of bricks / undecided words / columns, one launch per level) instead of
+ *                                  the one-launch hierarchical kernels
+ *                   cull (1)  the one-launch kernels on tile words skip whole bricks too (k_cull); 0 also switches `bricks` off
  *                   fused_hier (1), fused_boxes (1), fused_f32box (1)  table-free kernel: word rejection; boxes read /
  *                                  bounded on the fly in float32 / float64 intervals
  *                   fused_color_table (0)  table-free carve, survivors coloured from the colour camera's table (4 B per
@@ -204,6 +207,8 @@ int vc_fetch_mesh(vc_ctx *ctx, float *verts, uint32_t *faces);
  *                   refine_b (8), refine_blocks_per_cu (8), fused_blocks_per_cu (8)
  *   streams         overlap (1)  scan + record expansion of a step on a second stream, beside the next step's carve
  *                                  (single stream while a communicator is attached)
+ *   experiments     dbg (0)  bit 0: skip the per-voxel level (undecided words count as alive), bit 1: skip the word level
+ *                                  too -- WRONG results on purpose, to time the levels apart (scripts/exp_bricks.py)
  *   timing          timing_detail (0)  1: vc_carve_begin steps record the events around preparation and carve kernels too
  *                                  (vc_carve always does; see vc_timing_t)
  *   multi-GPU       gather_compact (1)  exchange occupancy words instead of records;

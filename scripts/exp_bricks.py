@@ -24,15 +24,15 @@ def t(mode, n=20, **opts):
     cnt = eng.count
     dc = eng.debug_counters()
     for k in opts:
-        eng.set_option(k, {"dbg": 0, "strips": 1, "cull": 1, "strips_per_wave": 1, "grid_lds_kb": 16}[k])
+        eng.set_option(k, {"dbg": 0, "bricks": 1, "cull": 1, "strips_per_wave": 1, "grid_lds_kb": 16}[k])
     return "%-6s %-40s carve %.4f ms  compact %.4f  survivors %d  %s" % (mode, opts, tm["carve_ms_sum"] / tm["carve_launches"], tm["compact_ms"], cnt, dc)
 for mode in ("lut",):
     print(t(mode))
     print(t(mode, dbg=1))
     print(t(mode, dbg=3))
-    print(t(mode, dbg=32))
-    print(t(mode, dbg=35))
+    
+    
 
-    print(t(mode, strips=0))
-    print(t(mode, strips=0, cull=0))
+    print(t(mode, bricks=0))
+    print(t(mode, bricks=0, cull=0))
 

@@ -167,7 +167,7 @@ def test_every_kernel_family_agrees_with_oracle(eng, seed):
     eng.upload_frame(2, frames3[2])
     eng.build_lut()
     try:
-        for opts in ({"lut_hier": 1}, {"strips": 0}, {"cull": 0}, {"lut_tile": 0}, {"fused_tile": 0}, {"fused_color_table": 1}, {"fused_boxes": 0}, {"fused_boxes": 0, "fused_f32box": 0},
+        for opts in ({"lut_hier": 1}, {"bricks": 0}, {"cull": 0}, {"lut_tile": 0}, {"fused_tile": 0}, {"fused_color_table": 1}, {"fused_boxes": 0}, {"fused_boxes": 0, "fused_f32box": 0},
                      {"fused_boxes": 0, "fused_tile": 0}, {"lut_hier": 0}, {"lut_hier": 0, "first_kv": 4}, {"lut_hier": 1, "refine_b": 16, "refine_pair": 0},
                      {"reorder": 0}, {"fused_hier": 0}, {"refine_pair": 0}, {"emit_lanes": 0}, {"emit_busy": 2}, {"emit_busy": 2, "lut_tile": 0, "fused_tile": 0},
                      {"force_generic": 1}):
@@ -182,9 +182,9 @@ def test_every_kernel_family_agrees_with_oracle(eng, seed):
                 assert np.array_equal(eng.fetch_occupancy(), occ), (opts, mode)
                 assert int(np.bitwise_count(eng.pack_entries()[:, 0]).sum()) == want["count"], (opts, mode)
             for k in opts:
-                eng.set_option(k, {"lut_hier": 1, "strips": 1, "cull": 1, "lut_tile": 1, "fused_tile": 1, "fused_f32box": 1, "fused_boxes": 1, "fused_color_table": 0, "first_kv": 1, "refine_b": 8, "reorder": 1, "fused_hier": 1, "refine_pair": 1, "emit_lanes": 1, "emit_busy": 1, "force_generic": 0}[k])
+                eng.set_option(k, {"lut_hier": 1, "bricks": 1, "cull": 1, "lut_tile": 1, "fused_tile": 1, "fused_f32box": 1, "fused_boxes": 1, "fused_color_table": 0, "first_kv": 1, "refine_b": 8, "reorder": 1, "fused_hier": 1, "refine_pair": 1, "emit_lanes": 1, "emit_busy": 1, "force_generic": 0}[k])
     finally:
-        for k, v in {"lut_hier": 1, "strips": 1, "cull": 1, "lut_tile": 1, "fused_tile": 1, "fused_f32box": 1, "fused_boxes": 1, "fused_color_table": 0, "first_kv": 1, "refine_b": 8, "reorder": 1, "fused_hier": 1, "refine_pair": 1, "emit_lanes": 1, "emit_busy": 1, "force_generic": 0}.items():
+        for k, v in {"lut_hier": 1, "bricks": 1, "cull": 1, "lut_tile": 1, "fused_tile": 1, "fused_f32box": 1, "fused_boxes": 1, "fused_color_table": 0, "first_kv": 1, "refine_b": 8, "reorder": 1, "fused_hier": 1, "refine_pair": 1, "emit_lanes": 1, "emit_busy": 1, "force_generic": 0}.items():
             eng.set_option(k, v)
     with pytest.raises(Exception):
         eng.set_option("no_such_option", 1)
@@ -722,12 +722,12 @@ def test_lut_file_round_trip_and_rejection(eng, cams, masks, frames, tmp_path):
         eng.load_lut(path)
         assert eng.carve(mode="lut") == want and np.array_equal(eng.fetch_records(), rec), grid
         assert np.array_equal(np.stack([eng.fetch_lut(c) for c in range(4)]), tables), grid
-        for opts in ({"lut_hier": 0}, {"force_generic": 1}, {"lut_tile": 0}, {"strips": 0}):   # every LUT kernel family reads the adopted table
+        for opts in ({"lut_hier": 0}, {"force_generic": 1}, {"lut_tile": 0}, {"bricks": 0}):   # every LUT kernel family reads the adopted table
             for k, v in opts.items():
                 eng.set_option(k, v)
             assert eng.carve(mode="lut") == want and np.array_equal(eng.fetch_records(), rec), (grid, opts)
             for k in opts:
-                eng.set_option(k, {"lut_hier": 1, "force_generic": 0, "lut_tile": 1, "strips": 1}[k])
+                eng.set_option(k, {"lut_hier": 1, "force_generic": 0, "lut_tile": 1, "bricks": 1}[k])
     # a foreign table: camera 3 blind in the upper half of the slab -- the carve follows the table, not the cameras
     grid = (16, 256, 20)
     setup_real(eng, cams, masks, frames, grid)

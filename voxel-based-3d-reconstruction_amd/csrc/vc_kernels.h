@@ -108,7 +108,8 @@ struct CarveParams {
     uint32_t nx, ny, nz, z0;
     uint32_t C, H, W, mwords;
     uint32_t min_views;
-    uint32_t dbg;               // experiments only (vc_set_option("dbg", ...)): 1 = skip the voxel level, 2 = skip the word level
+    uint32_t dbg;               // experiments only (vc_set_option("dbg", ...), scripts/exp_bricks.py): 1 = skip the voxel level (undecided words
+                                // count as alive), 2 = skip the word level too; results are then WRONG on purpose
     CamDev cam[kMaxCameras];
 };
 
@@ -1101,7 +1102,6 @@ struct BrickLists {
     uint32_t *host_counts;      // page-locked [4]
     uint32_t parity;
     uint32_t cap_b, cap_c, cap_w;   // shard capacities of the three lists (entries)
-    uint64_t *trace;            // experiments (dbg & 32): per wave of k_brick_words {entry, staged, done} in 10 ns ticks
 };
 
 // producer: space for popcount(mask) entries in shard `shard`; returns this lane's entry index (valid where its mask bit is set)
@@ -1222,7 +1222,6 @@ __global__ __launch_bounds__(kBlock) void k_brick_boxes_bm(const CarveParams p, 
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_brick_words(const CarveParams p, const BrickLists bl)
 {
     extern __shared__ uint32_t s_grid[];
-    const uint64_t tr0 = (p.dbg & 32u) ? wall_clock64() : 0ull;
     uint32_t *cnt = bl.counters + bl.parity * 3 * kShards * kShardStride;
     const ShardView sv = shard_view(cnt, 1, threadIdx.x & 63u);
     const uint32_t nlist = sv.total;
@@ -1242,7 +1241,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
     const uint32_t nwaves = gridDim.x * (kBlock / 64);
     const uint32_t qpl = p.nx >> 2, nzl = (uint32_t)(p.n / ((uint64_t)p.nx * p.ny));
-    const uint64_t tr1 = (p.dbg & 32u) ? wall_clock64() : 0ull;
     for (uint32_t t = wave0; t < nlist; t += nwaves) {
         uint32_t shard, within, ssize;
         shard_locate(sv, t, shard, within, ssize);
@@ -1278,9 +1276,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             const size_t o = shard_append(cnt + 2 * kShards * kShardStride, bl.cap_w, t % kShards, um, lane);
             if (need) bl.words[o] = T | ((uint64_t)need << 32);
         }
-    }
-    if ((p.dbg & 32u) && lane == 0 && wave0 < 16384u) {
-        bl.trace[3 * wave0] = tr0; bl.trace[3 * wave0 + 1] = tr1; bl.trace[3 * wave0 + 2] = wall_clock64();
     }
 }
 

@@ -203,7 +203,6 @@ struct vc_ctx {
     DevBuf<uint32_t> d_blist;        // counters [8] | brick list [nbrick_pad] | column list
     DevBuf<uint64_t> d_wlist;        // undecided words (worst case: every word of the slab)
     uint32_t *h_lists = nullptr;     // pinned [4]: list lengths of an earlier step, to size launches by
-    DevBuf<uint64_t> d_trace;        // experiments (dbg & 32)
     // marching cubes (vc_marching_cubes)
     DevBuf<uint64_t> d_mcbits, d_mcx;
     DevBuf<uint32_t> d_mcwbase, d_mcgv, d_mcgt, d_mcgvoff, d_mcgtoff, d_mcfaces;
@@ -212,7 +211,7 @@ struct vc_ctx {
     uint64_t mc_verts = 0, mc_faces = 0;
     bool mc_valid = false;
     uint32_t list_parity = 0;
-    int strips = 1;                  // carve by bricks where the grid shape allows (ny in {256, 512, 1024}); (option name kept)
+    int bricks = 1;                  // the brick pipeline where the grid shape allows (ny in {256, 512, 1024})
     int dbg = 0;
     bool kbox_valid = false;
     int cull = 1;                    // hierarchical kernels on tile words: cull whole bricks first
@@ -387,9 +386,9 @@ int build_brick_boxes(vc_ctx *ctx)
 }
 
 // Grid shapes the brick pipeline takes: a group of 4096 consecutive voxels must lie inside one brick column (see k_assemble).
-bool strip_shape(const vc_ctx *ctx, const CarveParams &p)
+bool brick_shape(const vc_ctx *ctx, const CarveParams &p)
 {
-    if (!ctx->strips || !ctx->cull || !ctx->kbox_valid) return false;
+    if (!ctx->bricks || !ctx->cull || !ctx->kbox_valid) return false;
     if (ctx->ny != 256 && ctx->ny != 512 && ctx->ny != 1024) return false;
     if (ctx->nx % (4096u / ctx->ny) != 0 || ctx->nx % 4 != 0) return false;
     return true;
@@ -435,12 +434,6 @@ int launch_bricks(vc_ctx *ctx, CarveParams &p, size_t lds, uint32_t ngroups)
     bl.wbox = ctx->d_wbox.ptr;
     bl.host_counts = ctx->h_lists;
     bl.parity = (ctx->list_parity ^= 1u);
-    bl.trace = nullptr;
-    if (ctx->dbg & 32) {
-        VC_TRY(ensure(ctx, ctx->d_trace, 3 * 16384));
-        VC_HIP(ctx, hipMemsetAsync(ctx->d_trace.ptr, 0, 3 * 16384 * sizeof(uint64_t), ctx->stream));
-        bl.trace = ctx->d_trace.ptr;
-    }
     p.live = ctx->d_live.ptr;
     const volatile uint32_t *known = ctx->h_lists;                // lengths of an earlier step (any size is correct: the waves stride)
     const uint32_t k_bricks = known[0], k_cols = known[1], k_words = known[2];
@@ -859,7 +852,7 @@ int vc_destroy(vc_ctx *ctx)
         if (s.e_up) (void)hipEventDestroy(s.e_up);
     }
     for (int k = 0; k < 2; ++k) if (ctx->ev_h[k]) (void)hipEventDestroy(ctx->ev_h[k]);
-    release(ctx->d_axes); release(ctx->d_morph); release(ctx->d_lut); release(ctx->d_bbox); release(ctx->d_lut_tile); release(ctx->d_tbox); release(ctx->d_kbox); release(ctx->d_live); release(ctx->d_wbox); release(ctx->d_bm); release(ctx->d_blist); release(ctx->d_wlist); release(ctx->d_trace);
+    release(ctx->d_axes); release(ctx->d_morph); release(ctx->d_lut); release(ctx->d_bbox); release(ctx->d_lut_tile); release(ctx->d_tbox); release(ctx->d_kbox); release(ctx->d_live); release(ctx->d_wbox); release(ctx->d_bm); release(ctx->d_blist); release(ctx->d_wlist);
     release(ctx->d_mcbits); release(ctx->d_mcx); release(ctx->d_mcwbase); release(ctx->d_mcgv); release(ctx->d_mcgt); release(ctx->d_mcgvoff);
     release(ctx->d_mcgtoff); release(ctx->d_mcfaces); release(ctx->d_mcbv); release(ctx->d_mcbvoff); release(ctx->d_mcbt); release(ctx->d_mcbtoff);
     release(ctx->d_mcverts);
@@ -1330,7 +1323,7 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
                     VC_HIP(ctx, hipMemsetAsync(sb.groupcnt.ptr, 0, sizeof(uint32_t) * ngroups, ctx->stream));
                     sb.sparse_words = false;
                 }
-                if (strip_shape(ctx, p)) {
+                if (brick_shape(ctx, p)) {
                     sb.sparse_words = true;              // (k_cull_bricks zeroes every group's count itself)
                     VC_TRY(launch_bricks<true>(ctx, p, lds, ngroups));
                 } else {
@@ -1383,7 +1376,7 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
                     VC_TRY(ensure_boxes(ctx, true));
                     p.tbox = ctx->d_tbox.ptr;
                     p.kbox = ctx->d_kbox.ptr;
-                    if (strip_shape(ctx, p)) {
+                    if (brick_shape(ctx, p)) {
                         sb.sparse_words = true;
                         VC_TRY(launch_bricks<false>(ctx, p, lds, ngroups));
                     } else {
@@ -1749,7 +1742,7 @@ int vc_set_option(vc_ctx *ctx, const char *name, int value)
     else if (k == "overlap") ctx->overlap = value != 0;
     else if (k == "timing_detail") ctx->timing_detail = value != 0;
     else if (k == "cull") ctx->cull = value != 0;
-    else if (k == "strips") ctx->strips = value != 0;
+    else if (k == "bricks") ctx->bricks = value != 0;
     else if (k == "dbg") ctx->dbg = value;
     else if (k == "emit_busy" && value >= 0 && value <= 2) ctx->emit_busy = value;          // 0 never, 1 large grids, 2 always
     else if (k == "emit_waves_per_cu" && value >= 4 && value <= 1024) ctx->emit_waves_per_cu = value;
@@ -1789,20 +1782,7 @@ int vc_debug_counters(vc_ctx *ctx, uint64_t out[8])
             out[0] += q[k * kShardStride]; out[4] += q[(kShards + k) * kShardStride]; out[5] += q[(2 * kShards + k) * kShardStride];
         }
     }
-    if ((ctx->dbg & 32) && ctx->d_trace.ptr) {
-        std::vector<uint64_t> tr(3 * 16384);
-        VC_HIP(ctx, hipMemcpy(tr.data(), ctx->d_trace.ptr, tr.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
-        uint64_t t0min = ~0ull, t2max = 0, sum_life = 0, max_life = 0, sum_stage = 0, nwv = 0;
-        for (size_t i = 0; i < 16384; ++i) {
-            if (!tr[3 * i + 2]) continue;
-            ++nwv;
-            t0min = tr[3 * i] < t0min ? tr[3 * i] : t0min; t2max = tr[3 * i + 2] > t2max ? tr[3 * i + 2] : t2max;
-            const uint64_t life = tr[3 * i + 2] - tr[3 * i];
-            sum_life += life; max_life = life > max_life ? life : max_life; sum_stage += tr[3 * i + 1] - tr[3 * i];
-        }
-        if (nwv) { out[6] = ((t2max - t0min) << 32) | (sum_life / nwv); out[7] = (max_life << 32) | (sum_stage / nwv); out[3] = nwv; }
-    }
-    if (ctx->d_live.ptr && ctx->kbox_valid && !(ctx->dbg & 32)) {
+    if (ctx->d_live.ptr && ctx->kbox_valid) {
         const size_t nw = p.nbrick_pad / 64;
         std::vector<uint64_t> bits(2 * nw);
         VC_HIP(ctx, hipMemcpy(bits.data(), ctx->d_live.ptr, bits.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));

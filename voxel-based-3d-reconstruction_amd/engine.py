@@ -302,8 +302,7 @@ class CarveEngine:
         out = np.zeros(8, dtype=np.uint64)
         self._check(self._L.vc_debug_counters(self._ctx, _ptr(out, ctypes.c_uint64)), "vc_debug_counters")
         return {"bricks_listed": int(out[0]), "bricks_live": int(out[1]), "bricks_full": int(out[2]), "bricks": int(out[3]),
-                "columns_listed": int(out[4]), "words_undecided": int(out[5]),
-                "trace_span_mean_10ns": (int(out[6]) >> 32, int(out[6]) & 0xffffffff), "trace_maxlife_meanstage_10ns": (int(out[7]) >> 32, int(out[7]) & 0xffffffff)}
+                "columns_listed": int(out[4]), "words_undecided": int(out[5])}
 
     def synchronize(self):
         self._check(self._L.vc_synchronize(self._ctx), "vc_synchronize")
