@@ -107,11 +107,15 @@ struct Slot {
     uint32_t parity = 0;        // which of the header's two foreground-box sets the current frame filled
     bool counts_zero = false;   // the header's sample counts are zero (k_prep_pack just ran)
     hipEvent_t e_up = nullptr;  // last upload into this slot (owned; upload stream)
+    // The per-frame preparation runs on the UPLOAD stream, right behind the copy it works on and beside whatever the carve
+    // stream is doing for the step before; e_prep (owned) marks its end, the carve waits for it.  e_p0: its start when timed.
+    hipEvent_t e_prep = nullptr, e_p0 = nullptr;
+    bool prep_pending = false, prep_timed = false;
     // borrowed from the step that used the slot last (recording an event between two kernels costs ~10 us of stream time,
-    // so the slot rides on the events a step records anyway): a point behind the last kernel that read the uploaded
-    // bytes, and one behind the last record expansion that read the slot's bits / images on the second stream
-    hipEvent_t e_read = nullptr, e_emit = nullptr;
-    bool up_pending = false, read_pending = false, emit_pending = false;
+    // so the slot rides on events a step records anyway): behind the last carve kernels that read the slot's bits / grids,
+    // and behind the last record expansion that read its bits / images on the second stream.  The next preparation waits for both.
+    hipEvent_t e_carve = nullptr, e_emit = nullptr;
+    bool up_pending = false, carve_pending = false, emit_pending = false;
 };
 
 // np.linspace(lo, hi, num=n) in float64: y[k] = k*step + lo (two roundings), y[n-1] = hi
@@ -458,6 +462,8 @@ int slot_at(vc_ctx *ctx, uint32_t slot, Slot **out)
     if (s.have_frame.size() != ctx->C) { s.have_frame.assign(ctx->C, 0); s.frame_dirty.assign(ctx->C, 0); }
     if (!s.e_up) {
         VC_HIP(ctx, hipEventCreateWithFlags(&s.e_up, hipEventDisableTiming));
+        VC_HIP(ctx, hipEventCreate(&s.e_prep));
+        VC_HIP(ctx, hipEventCreate(&s.e_p0));
     }
     *out = &s;
     return VC_OK;
@@ -477,29 +483,35 @@ void release_slot(Slot &s)
 
 uint32_t grid_for(uint64_t n);
 
-// Queues, on the carve stream, whatever the slot's derived state is missing: bit masks + BGRX images + grid plan
-// (k_prep_pack, after the optional 2x2 post-filter), and for the chunked / hierarchical kernels the block grids and
-// the camera order (k_prep_grid).  No host synchronisation: the kernels leave their results in the slot's header.
-int ensure_prepared(vc_ctx *ctx, Slot &s, bool want_grids, const CarveParams *cp)
+// Queues, on the UPLOAD stream (behind the copy of the bytes it reads, beside the carve stream's work for the step before),
+// whatever the slot's derived state is missing: bit masks + BGRX images + grid plan (k_prep_pack, after the optional 2x2
+// post-filter), and for the chunked / hierarchical kernels the block grids and the camera order (k_prep_grid).  No host
+// synchronisation: the kernels leave their results in the slot's header; e_prep marks their end for the carve stream.
+int ensure_prepared(vc_ctx *ctx, Slot &s, bool want_grids, const CarveParams *cp, bool timed = false)
 {
     const uint32_t C = ctx->C;
     const size_t HW = (size_t)ctx->H * ctx->W;
+    hipStream_t st = ctx->stream_up;
+    if (s.bits_valid && !(want_grids && !s.grids_valid)) return VC_OK;
+    // the kernels that still read what is about to be overwritten: carve kernels (bits, grids), record expansion (bits, images)
+    if (s.carve_pending) { VC_HIP(ctx, hipStreamWaitEvent(st, s.e_carve, 0)); s.carve_pending = false; }
+    if (s.emit_pending) { VC_HIP(ctx, hipStreamWaitEvent(st, s.e_emit, 0)); s.emit_pending = false; }
+    s.prep_timed = timed;
+    if (timed) VC_HIP(ctx, hipEventRecord(s.e_p0, st));
     if (!s.bits_valid) {
-        if (s.up_pending) VC_HIP(ctx, hipStreamWaitEvent(ctx->stream, s.e_up, 0));
-        if (s.emit_pending) { VC_HIP(ctx, hipStreamWaitEvent(ctx->stream, s.e_emit, 0)); s.emit_pending = false; }
         VC_TRY(ensure(ctx, s.bits, (size_t)ctx->mwords * C));
         uint32_t budget = (uint32_t)ctx->grid_lds_kb * 256u;                  // u32 words of header + grids
         if (budget < kGridHeader + 128u) budget = kGridHeader + 128u;         // room for every camera's grid at the coarsest block
         if (budget + 8 > s.grid.cap || !s.grid.ptr) {
             VC_TRY(ensure(ctx, s.grid, (size_t)budget + 8));                   // + padding: kernels copy it 16 bytes at a time
-            VC_HIP(ctx, hipMemsetAsync(s.grid.ptr, 0, s.grid.cap * sizeof(uint32_t), ctx->stream));
+            VC_HIP(ctx, hipMemsetAsync(s.grid.ptr, 0, s.grid.cap * sizeof(uint32_t), st));
         }
         if (!s.boxes.ptr) {
             VC_TRY(ensure(ctx, s.boxes, (size_t)2 * kMaxCameras * kBoxStride));
             std::vector<uint32_t> init(s.boxes.cap, 0u);                       // both box sets start empty
             for (uint32_t k = 0; k < 2 * kMaxCameras; ++k) { init[kBoxStride * k] = 0xffffffffu; init[kBoxStride * k + 2] = 0xffffffffu; }
-            VC_HIP(ctx, hipMemcpyAsync(s.boxes.ptr, init.data(), init.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-            VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            VC_HIP(ctx, hipMemcpyAsync(s.boxes.ptr, init.data(), init.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+            VC_HIP(ctx, hipStreamSynchronize(st));
             s.parity = 0;
         }
         s.budget_words = budget;
@@ -516,13 +528,13 @@ int ensure_prepared(vc_ctx *ctx, Slot &s, bool want_grids, const CarveParams *cp
             uint8_t *fin = ctx->d_morph.ptr + HW * c, *tmp = ctx->d_morph.ptr + HW * C;
             const dim3 mg(grid_for(HW)), mb(kBlock);
             if (ctx->post_open[c]) {
-                hipLaunchKernelGGL((k_morph2x2<false>), mg, mb, 0, ctx->stream, img, tmp, ctx->H, ctx->W);
-                hipLaunchKernelGGL((k_morph2x2<true>), mg, mb, 0, ctx->stream, (const uint8_t *)tmp, fin, ctx->H, ctx->W);
+                hipLaunchKernelGGL((k_morph2x2<false>), mg, mb, 0, st, img, tmp, ctx->H, ctx->W);
+                hipLaunchKernelGGL((k_morph2x2<true>), mg, mb, 0, st, (const uint8_t *)tmp, fin, ctx->H, ctx->W);
                 img = fin;
             }
             if (ctx->post_close[c]) {
-                hipLaunchKernelGGL((k_morph2x2<true>), mg, mb, 0, ctx->stream, img, tmp, ctx->H, ctx->W);
-                hipLaunchKernelGGL((k_morph2x2<false>), mg, mb, 0, ctx->stream, (const uint8_t *)tmp, fin, ctx->H, ctx->W);
+                hipLaunchKernelGGL((k_morph2x2<true>), mg, mb, 0, st, img, tmp, ctx->H, ctx->W);
+                hipLaunchKernelGGL((k_morph2x2<false>), mg, mb, 0, st, (const uint8_t *)tmp, fin, ctx->H, ctx->W);
             }
             VC_HIP(ctx, hipGetLastError());
             pp.src[c] = fin;
@@ -542,9 +554,8 @@ int ensure_prepared(vc_ctx *ctx, Slot &s, bool want_grids, const CarveParams *cp
         pp.iters = (uint32_t)(total_words / (256ull * 1024ull));
         pp.iters = pp.iters < 1 ? 1 : (pp.iters > 16 ? 16 : pp.iters);
         const uint32_t pw = (ctx->mwords + kBlock * pp.iters - 1) / (kBlock * pp.iters), fw = (uint32_t)((HW + 4 * kBlock - 1) / (4 * kBlock));
-        hipLaunchKernelGGL(k_prep_pack, dim3(C * pw + pp.nframes * fw), dim3(kBlock), 0, ctx->stream, pp);
+        hipLaunchKernelGGL(k_prep_pack, dim3(C * pw + pp.nframes * fw), dim3(kBlock), 0, st, pp);
         VC_HIP(ctx, hipGetLastError());
-        s.read_pending = false;          // the caller points e_read at an event it records behind these kernels
         s.bits_valid = true;
         s.grids_valid = false;
         s.counts_zero = true;
@@ -555,15 +566,17 @@ int ensure_prepared(vc_ctx *ctx, Slot &s, bool want_grids, const CarveParams *cp
         const uint64_t n = p.n;
         const uint32_t ns = (uint32_t)(n < kEstimateSamples ? n : kEstimateSamples);
         const uint32_t est_wgs = ctx->reorder ? (ns + kBlock * kEstPerThread - 1) / (kBlock * kEstPerThread) : 0u;   // no counts: cameras in index order
-        if (!s.counts_zero) VC_HIP(ctx, hipMemsetAsync(s.grid.ptr + kHdrCount, 0, sizeof(uint32_t) * kMaxCameras, ctx->stream));
+        if (!s.counts_zero) VC_HIP(ctx, hipMemsetAsync(s.grid.ptr + kHdrCount, 0, sizeof(uint32_t) * kMaxCameras, st));
         s.counts_zero = false;
         // a camera's grids hold at most 16 blocks per budgeted word
         const uint32_t grid_wgs = (16u * s.budget_words + kBlock - 1) / kBlock;
-        hipLaunchKernelGGL(k_prep_grid, dim3(grid_wgs > est_wgs ? grid_wgs : est_wgs, C + (est_wgs ? 1 : 0)), dim3(kBlock), 0, ctx->stream, p,
+        hipLaunchKernelGGL(k_prep_grid, dim3(grid_wgs > est_wgs ? grid_wgs : est_wgs, C + (est_wgs ? 1 : 0)), dim3(kBlock), 0, st, p,
                            s.grid.ptr, (const uint32_t *)s.boxes.ptr, s.parity, (uint32_t)ctx->grid_min_shift, s.budget_words, ns);
         VC_HIP(ctx, hipGetLastError());
         s.grids_valid = true;
     }
+    VC_HIP(ctx, hipEventRecord(s.e_prep, st));
+    s.prep_pending = true;
     return VC_OK;
 }
 
@@ -850,6 +863,8 @@ int vc_destroy(vc_ctx *ctx)
     for (Slot &s : ctx->slots) {
         release_slot(s);
         if (s.e_up) (void)hipEventDestroy(s.e_up);
+        if (s.e_prep) (void)hipEventDestroy(s.e_prep);
+        if (s.e_p0) (void)hipEventDestroy(s.e_p0);
     }
     for (int k = 0; k < 2; ++k) if (ctx->ev_h[k]) (void)hipEventDestroy(ctx->ev_h[k]);
     release(ctx->d_axes); release(ctx->d_morph); release(ctx->d_lut); release(ctx->d_bbox); release(ctx->d_lut_tile); release(ctx->d_tbox); release(ctx->d_kbox); release(ctx->d_live); release(ctx->d_wbox); release(ctx->d_bm); release(ctx->d_blist); release(ctx->d_wlist);
@@ -993,7 +1008,6 @@ static int stage_upload(vc_ctx *ctx, Slot &s, uint8_t **h_stage, size_t *h_cap, 
         if (h_cap) *h_cap = bytes;
     }
     memcpy(*h_stage, src, bytes);
-    if (s.read_pending) { VC_HIP(ctx, hipStreamWaitEvent(ctx->stream_up, s.e_read, 0)); s.read_pending = false; }
     if (timed) {
         if (ctx->h2d_pending) { (void)hipEventSynchronize(ctx->ev_h[1]); (void)hipEventElapsedTime(&ctx->tm.h2d_ms, ctx->ev_h[0], ctx->ev_h[1]); }
         VC_HIP(ctx, hipEventRecord(ctx->ev_h[0], ctx->stream_up));
@@ -1049,7 +1063,7 @@ int vc_fetch_mask(vc_ctx *ctx, uint32_t slot, uint32_t cam, uint8_t *out)
     if (cam >= ctx->C) return fail(ctx, VC_ERR_ARG, "camera %u not in [0,%u)", cam, ctx->C);
     VC_HIP(ctx, hipSetDevice(ctx->device));
     VC_TRY(ensure_prepared(ctx, ctx->slots[slot], false, nullptr));
-    VC_HIP(ctx, hipStreamSynchronize(ctx->stream));       // (nothing reads the uploaded bytes any more)
+    VC_HIP(ctx, hipStreamSynchronize(ctx->stream_up));
     std::vector<uint32_t> bits(ctx->mwords);
     VC_HIP(ctx, hipMemcpy(bits.data(), ctx->slots[slot].bits.ptr + (size_t)cam * ctx->mwords, sizeof(uint32_t) * ctx->mwords,
                           hipMemcpyDeviceToHost));
@@ -1291,9 +1305,8 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     sb.prepped = !s.bits_valid || (fast && !s.grids_valid);
     sb.carve_timed = ctx->timing_detail || ctx->sync_call;
     sb.prep_timed = sb.prepped && sb.carve_timed;
-    if (sb.prep_timed) VC_HIP(ctx, hipEventRecord(sb.e_prep, ctx->stream));
-    const bool read_bytes = !s.bits_valid;
-    VC_TRY(ensure_prepared(ctx, s, fast, &p));
+    VC_TRY(ensure_prepared(ctx, s, fast, &p, sb.prep_timed));
+    if (s.prep_pending) { VC_HIP(ctx, hipStreamWaitEvent(ctx->stream, s.e_prep, 0)); s.prep_pending = false; }
     p.maskbits = s.bits.ptr;
     p.blockgrid = s.grid.ptr;
     // which table the step reads: the tile-ordered one (hierarchical kernels on tile words), else the y-major one
@@ -1482,7 +1495,7 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
         VC_HIP(ctx, hipEventRecord(sb.e_scan, ctx->stream));     // cross-stream dependency; with e2 it also brackets the expansion
         if (s3 != ctx->stream) VC_HIP(ctx, hipStreamWaitEvent(s3, sb.e_scan, 0));
         sb.emit_timed = true;
-        if (read_bytes) { s.e_read = sb.e_scan; s.read_pending = true; }   // an upload into this slot waits for the kernels that read its bytes
+        s.e_carve = sb.e_scan; s.carve_pending = true;           // the slot's next preparation waits for the kernels that read its bits / grids
     }
     if (!sb.no_records) {
         VC_TRY(launch_emit(ctx, sb, s3));
@@ -1494,7 +1507,7 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     }
     VC_HIP(ctx, hipEventRecord(sb.e2, sb.no_records ? s2 : s3));
     if (!sb.no_records && s3 != ctx->stream) { s.e_emit = sb.e2; s.emit_pending = true; }   // the expansion reads the slot's bits / images
-    if (read_bytes && !s.read_pending) { s.e_read = sb.e2; s.read_pending = true; }          // (no e_scan recorded: e2 is behind the preparation too)
+    if (!s.carve_pending) { s.e_carve = sb.e2; s.carve_pending = true; }                       // (no e_scan recorded: e2 is behind the carve kernels too)
     sb.pending = true;
     sb.used = true;
     ctx->head ^= 1;
@@ -1544,7 +1557,8 @@ int vc_carve_end(vc_ctx *ctx, uint64_t *n_out)
         ctx->tm.prep_ms = 0;
         if (sb.prepped) ctx->tm.preps += 1;
         if (sb.prep_timed) {
-            VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.prep_ms, sb.e_prep, sb.e0));
+            Slot &sl = ctx->slots[sb.slot];
+            VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.prep_ms, sl.e_p0, sl.e_prep));
             ctx->tm.prep_ms_sum += ctx->tm.prep_ms;
             ctx->tm.preps_timed += 1;
         }
