@@ -303,11 +303,19 @@ def main():
         # rendezvous directory and all act on the same list -- a rank that failed alone cannot wander off to another
         # transport while the others sit in a collective
         err = ""
+        # RCCL prints a version banner on STDOUT when it starts (NCCL_DEBUG=VERSION in this image): rank 0's stdout must
+        # carry the one JSON line and nothing else, so file descriptor 1 points at stderr while the communicator comes up
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         try:
             uid = slabs.file_rendezvous(grp.rank, voxcarve.CarveEngine.comm_unique_id() if grp.rank == 0 else None)
             eng.comm_init(grp.world, grp.rank, uid)
         except Exception as exc:
             err = str(exc)[:300] or type(exc).__name__
+        finally:
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
         flags = slabs.file_all_flags(grp.rank, grp.world, "comm", err)
         if all(f == "" for f in flags):
             grp.attach(eng)
