@@ -201,8 +201,8 @@ int vc_fetch_mesh(vc_ctx *ctx, float *verts, uint32_t *faces);
  *                   refine_pair (1), reorder (1)  two cameras per round trip; most selective camera first
  *                   emit_lanes (1), emit_busy (1: grids >= 64 M voxels, 2: always, 0: never)  record expansion form
  *                   force_generic (0)  one thread per voxel everywhere (also env VOXCARVE_FORCE_GENERIC=1)
- *   frame sets      grid_lds_kb (16), grid_min_shift (1)  LDS budget / finest block of the cropped block grids
- *                                  (read by the next vc_upload_masks)
+ *   frame sets      grid_lds_kb (0 = 16, or 64 for frame sets above 2 MB of mask bits), grid_min_shift (1)  LDS budget / finest
+ *                                  block of the cropped block grids (read when a frame set is next prepared)
  *   launch shape    hier_blocks_per_cu (48), emit_waves_per_cu (256), first_kv (1), first_blocks_per_cu (3),
  *                   refine_b (8), refine_blocks_per_cu (8), fused_blocks_per_cu (8)
  *   streams         overlap (1)  scan + record expansion of a step on a second stream, beside the next step's carve

@@ -285,7 +285,7 @@ def test_config5_full_size_512_cubed_16_cameras_1080p(eng):
             idx, rgb, seen = voxcarve_unpack(rec)
             assert np.array_equal(idx, want["idx"]) and np.array_equal(rgb[:, ::-1], want["bgr"]) and seen.all(), (mode, lds)
             digest = hashlib.sha256(rec.tobytes()).hexdigest()
-    eng.set_option("grid_lds_kb", 16)
+    eng.set_option("grid_lds_kb", 0)
     eng.touch_masks(0)
     ents = []
     for r in range(8):

@@ -221,7 +221,7 @@ struct vc_ctx {
     int cull = 1;                    // hierarchical kernels on tile words: cull whole bricks first
     bool tile_valid = false;
     bool bbox_valid = false, tbox_valid = false;   // boxes match the grid, slab and cameras (also built without a table)
-    int grid_lds_kb = 16;            // LDS budget of a frame set's block grids (picks their resolution at upload)
+    int grid_lds_kb = 0;             // LDS budget of a frame set's block grids (picks their resolution); 0 = by frame-set size (16 or 64)
     int grid_min_shift = 1;          // finest block: 2^shift pixels
     int lut_tile = 1;                // hierarchical LUT kernel on tile words (needs nx % 4 == 0, ny % 64 == 0)
     int fused_tile = 1;              // the same word shape for the hierarchical table-free kernel
@@ -443,8 +443,15 @@ int launch_bricks(vc_ctx *ctx, CarveParams &p, size_t lds, uint32_t ngroups)
     const uint32_t k_bricks = known[0], k_cols = known[1], k_words = known[2];
     const uint32_t cw = p.nbrick_pad / 256;
     const dim3 block(kBlock);
-    hipLaunchKernelGGL(k_cull_bricks, dim3(cw < 1 ? 1 : (cw > 1024 ? 1024 : cw)), block, lds, ctx->stream, p, bl, ngroups);
-    hipLaunchKernelGGL(k_brick_words, dim3(sized(k_bricks, p.nbrick_pad / 8, p.nbrick_pad, 4)), block, lds, ctx->stream, p, bl);
+    // workgroups that stage the grids in LDS: no more than fit the chip at once when the grids are large (they stride over the lists)
+    const uint32_t fit = 256u * (uint32_t)(kLdsBytes / (lds ? lds : 1) < 1 ? 1 : kLdsBytes / (lds ? lds : 1));
+    const uint32_t lds_cap = lds > 20480 ? fit : 65536u;
+    uint32_t cull_wgs = cw < 1 ? 1 : (cw > 1024 ? 1024 : cw);
+    if (cull_wgs > lds_cap) cull_wgs = lds_cap;
+    uint32_t word_wgs = sized(k_bricks, p.nbrick_pad / 8, p.nbrick_pad, 4);
+    if (word_wgs > lds_cap) word_wgs = lds_cap;
+    hipLaunchKernelGGL(k_cull_bricks, dim3(cull_wgs), block, lds, ctx->stream, p, bl, ngroups);
+    hipLaunchKernelGGL(k_brick_words, dim3(word_wgs), block, lds, ctx->stream, p, bl);
     hipLaunchKernelGGL((k_voxel_words<LUT>), dim3(sized(k_words, (uint64_t)p.nbrick_pad * 4, (uint64_t)p.nbrick_pad * 64, 32)), block, 0,
                        ctx->stream, p, bl);
     hipLaunchKernelGGL(k_assemble, dim3(sized(k_cols == 0xffffffffu ? k_cols : k_cols * 16u, (uint64_t)ncolumns * 4, (uint64_t)ncolumns * 16, 4)),
@@ -500,7 +507,22 @@ int ensure_prepared(vc_ctx *ctx, Slot &s, bool want_grids, const CarveParams *cp
     if (timed) VC_HIP(ctx, hipEventRecord(s.e_p0, st));
     if (!s.bits_valid) {
         VC_TRY(ensure(ctx, s.bits, (size_t)ctx->mwords * C));
+        // LDS budget of header + grids: 16 KB (eight workgroups per CU) unless the frame set is so large that 16 KB would
+        // force blocks of 32 x 32 pixels on it (16 cameras at 1080p); the kernels that stage the grids are launched with
+        // few, persistent workgroups in that case
         uint32_t budget = (uint32_t)ctx->grid_lds_kb * 256u;                  // u32 words of header + grids
+        if (ctx->grid_lds_kb == 0) {
+            budget = 16u * 256u;
+            if ((uint64_t)ctx->mwords * C * 4 > (2u << 20)) {
+                // what the UNCROPPED grids of all cameras take at the finest block that keeps them within 64 KB: cropping can
+                // then only make the blocks finer, and the workgroups do not reserve more LDS than the grids can fill
+                for (uint32_t sh = (uint32_t)ctx->grid_min_shift; sh < 15; ++sh) {
+                    const uint64_t bw = ((uint64_t)ctx->W + (1u << sh) - 1) >> sh, bh = ((uint64_t)ctx->H + (1u << sh) - 1) >> sh;
+                    const uint64_t total = kGridHeader + (uint64_t)C * 2 * ((bw + 31) / 32) * bh;
+                    if (total <= 64u * 256u || sh == 14) { budget = (uint32_t)(total < 16u * 256u ? 16u * 256u : total); break; }
+                }
+            }
+        }
         if (budget < kGridHeader + 128u) budget = kGridHeader + 128u;         // room for every camera's grid at the coarsest block
         if (budget + 8 > s.grid.cap || !s.grid.ptr) {
             VC_TRY(ensure(ctx, s.grid, (size_t)budget + 8));                   // + padding: kernels copy it 16 bytes at a time
@@ -1761,7 +1783,7 @@ int vc_set_option(vc_ctx *ctx, const char *name, int value)
     else if (k == "emit_busy" && value >= 0 && value <= 2) ctx->emit_busy = value;          // 0 never, 1 large grids, 2 always
     else if (k == "emit_waves_per_cu" && value >= 4 && value <= 1024) ctx->emit_waves_per_cu = value;
     else if (k == "lut_tile") ctx->lut_tile = value != 0;
-    else if (k == "grid_lds_kb" && value >= 1 && value <= 64) ctx->grid_lds_kb = value;
+    else if (k == "grid_lds_kb" && value >= 0 && value <= 64) ctx->grid_lds_kb = value;
     else if (k == "grid_min_shift" && value >= 0 && value <= 8) ctx->grid_min_shift = value;
     else if (k == "fused_tile") ctx->fused_tile = value != 0;
     else if (k == "fused_f32box") ctx->fused_f32box = value != 0;
