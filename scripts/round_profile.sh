@@ -29,13 +29,14 @@ for f in sorted(glob.glob(out + "/pmc_*/*/*counter_collection.csv")):
         agg[k][0] += 1; agg[k][1] += float(r["Counter_Value"])
 rows = {}
 for (kn, cn), (n, v) in sorted(agg.items()):
-    if any(t in kn for t in ("k_lut", "k_carve", "k_emit", "k_scan", "k_build", "k_prep", "k_finish", "k_cull")):
+    if any(t in kn for t in ("k_lut", "k_carve", "k_emit", "k_scan", "k_build", "k_prep", "k_finish", "k_cull", "k_brick", "k_voxel", "k_assemble")):
         print("%-42s %-18s calls=%3d avg=%.6g" % (kn, cn, n, v / n))
         rows.setdefault(kn, {})[cn] = v / n
 json.dump(rows, open(out + "/pmc_summary.json", "w"), indent=1)
-# HBM bytes per launch of the dominant kernels (FETCH_SIZE doubled: profiles/r01_fetch_size_calibration.txt)
+# HBM bytes per launch of the kernels bench.py builds its roofline objects on (FETCH_SIZE doubled: profiles/r01_fetch_size_calibration.txt)
 traffic = {}
-for key, needle in (("lut_1024_g1", "k_lut_refine<8, true"), ("lut_stream_1024_g1", "k_lut_first")):
+for key, needle in (("emit_lut_real_1024x1024x1024_g1", "k_emit_busy<true, true"), ("emit_fused_real_1024x1024x1024_g1", "k_emit_busy<false, true"),
+                    ("lut_stream_real_1024x1024x1024_g1", "k_lut_first")):
     for kn, d in rows.items():
         if needle in kn and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
             rd, wr = d["FETCH_SIZE"] * 1024 * 2, d["WRITE_SIZE"] * 1024
