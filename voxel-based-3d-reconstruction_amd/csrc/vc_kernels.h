@@ -47,25 +47,27 @@ struct GridCam {
 // VGPRs), the block size and buffer length the preparation chose, and the camera visiting order.
 constexpr uint32_t kHdrShift = 3 * kMaxCameras;        // log2 of the block edge in pixels
 constexpr uint32_t kHdrWords = kHdrShift + 1;          // u32 words of header + grids (what the hierarchical kernels stage in LDS)
-constexpr uint32_t kHdrCount = kHdrShift + 4;          // kMaxCameras pass counts of a voxel sample: the camera visiting order
-constexpr uint32_t kGridHeader = kHdrCount + kMaxCameras;   // 68 words = 17 x 16 bytes
-// The cameras' foreground pixel boxes (k_prep_pack -> k_prep_grid) live beside the header, one 128-byte line per camera so
-// that the workgroups of different cameras do not meet on a line, double-buffered by frame parity: [2][kMaxCameras][kBoxStride].
+constexpr uint32_t kGridHeader = kHdrShift + 4;        // 52 words = 13 x 16 bytes
+// Beside the header, one 128-byte line per camera and quantity so that atomics of different cameras never meet on a line
+// (atomics on one LINE serialise at ~12 ns each): the cameras' foreground pixel boxes (k_prep_pack -> k_prep_grid),
+// double-buffered by frame parity, [2][kMaxCameras][kBoxStride]; then the pass counts of a voxel sample, [kMaxCameras][kBoxStride]
+// (k_prep_grid -> the carve kernels' camera visiting order).
 constexpr uint32_t kBoxStride = 32;
+constexpr uint32_t kCountBase = 2 * kMaxCameras * kBoxStride;
 __device__ __forceinline__ uint32_t hdr_u32(const uint32_t *hdr, uint32_t i)          // wave-uniform i
 {
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr[i]);
 }
-// Camera visiting order (most selective first) from the pass counts k_prep_grid left in the header: position of
+// Camera visiting order (most selective first) from the pass counts k_prep_grid left beside the header: position of
 // camera t = number of cameras with a smaller count (ties: lower camera number first).  Every workgroup works it
 // out for itself (C <= 16) into s_order; ends with a barrier.
-__device__ __forceinline__ void stage_order(const uint32_t *hdr, uint32_t C, uint32_t *s_order)
+__device__ __forceinline__ void stage_order(const uint32_t *counts, uint32_t C, uint32_t *s_order)
 {
     if (threadIdx.x < C) {
-        const uint32_t mine = hdr[kHdrCount + threadIdx.x];
+        const uint32_t mine = counts[threadIdx.x * kBoxStride];
         uint32_t rank = 0;
         for (uint32_t c = 0; c < C; ++c) {
-            const uint32_t o = hdr[kHdrCount + c];
+            const uint32_t o = counts[c * kBoxStride];
             rank += (o < mine || (o == mine && c < threadIdx.x)) ? 1u : 0u;
         }
         s_order[rank] = threadIdx.x;
@@ -98,6 +100,7 @@ struct CarveParams {
     uint64_t *live;             // [2][nbrick_pad / 64]: bit per brick "may hold survivors", then "every voxel survives"; null: no culling
     uint32_t nbx, nbz;          // bricks along x and (slab-local) z; along y there are tq
     uint32_t nbrick_pad;        // bricks rounded up to 64
+    const uint32_t *counts;     // the frame set's per-camera pass counts of a voxel sample, kBoxStride apart (camera visiting order)
     const uint32_t *blockgrid;  // the frame set's header (block size, length, camera order) + per camera (crop[c].off):
                                 // any[ch][cws] then all[ch][cws], one bit per block of 2^shift x 2^shift pixels
     uint64_t *words;
@@ -251,9 +254,9 @@ __global__ __launch_bounds__(kFirstBlock) void k_lut_first(const CarveParams p)
     extern __shared__ uint32_t s_mask[];                         // first camera's mask bits
     uint32_t c0 = 0;                                              // the most selective camera (lowest pass count)
     {
-        uint32_t best = hdr_u32(p.blockgrid, kHdrCount);
+        uint32_t best = hdr_u32(p.counts, 0);
         for (uint32_t c = 1; c < p.C; ++c) {
-            const uint32_t v = hdr_u32(p.blockgrid, kHdrCount + c);
+            const uint32_t v = hdr_u32(p.counts, c * kBoxStride);
             if (v < best) { best = v; c0 = c; }
         }
     }
@@ -422,7 +425,7 @@ __device__ __forceinline__ void lut_refine_body(const CarveParams &p, uint32_t v
         __syncthreads();
     }
     __shared__ uint32_t s_order[kMaxCameras];
-    stage_order(HIER ? s_grid : p.blockgrid, p.C, s_order);       // camera order (and block size) of this frame set
+    stage_order(p.counts, p.C, s_order);       // camera order (and block size) of this frame set
     const uint32_t gshift = HIER ? hdr_u32(s_grid, kHdrShift) : 0u;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane((vblock * kBlock + threadIdx.x) >> 6);
@@ -574,7 +577,7 @@ template <int KSUB, bool NY64>
 __global__ __launch_bounds__(kBlock) void k_carve_fused(const CarveParams p)
 {
     __shared__ uint32_t s_order[kMaxCameras];
-    stage_order(p.blockgrid, p.C, s_order);
+    stage_order(p.counts, p.C, s_order);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
     const uint32_t nwaves = gridDim.x * (kBlock / 64);
@@ -790,7 +793,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         __syncthreads();
     }
     __shared__ uint32_t s_order[kMaxCameras];
-    stage_order(s_grid, p.C, s_order);
+    stage_order(p.counts, p.C, s_order);
     const uint32_t gshift = hdr_u32(s_grid, kHdrShift);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
@@ -1036,7 +1039,7 @@ __global__ __launch_bounds__(kBlock) void k_cull(const CarveParams p)
         __syncthreads();
     }
     __shared__ uint32_t s_order[kMaxCameras];
-    stage_order(s_grid, p.C, s_order);
+    stage_order(p.counts, p.C, s_order);
     const uint32_t gshift = hdr_u32(s_grid, kHdrShift);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
@@ -1143,7 +1146,7 @@ __global__ __launch_bounds__(kBlock) void k_cull_bricks(const CarveParams p, con
         __syncthreads();
     }
     __shared__ uint32_t s_order[kMaxCameras];
-    stage_order(s_grid, p.C, s_order);
+    stage_order(p.counts, p.C, s_order);
     if (blockIdx.x == 0 && threadIdx.x < 3 * kShards) bl.counters[((bl.parity ^ 1u) * 3 * kShards + threadIdx.x) * kShardStride] = 0;
     uint32_t *cnt = bl.counters + bl.parity * 3 * kShards * kShardStride;
     const uint32_t gshift = hdr_u32(s_grid, kHdrShift);
@@ -1235,7 +1238,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         __syncthreads();
     }
     __shared__ uint32_t s_order[kMaxCameras];
-    stage_order(s_grid, p.C, s_order);
+    stage_order(p.counts, p.C, s_order);
     const uint32_t gshift = hdr_u32(s_grid, kHdrShift);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
@@ -1454,7 +1457,7 @@ __global__ __launch_bounds__(kBlock) void k_prep_pack(const PrepParams p)
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (blockIdx.x == 0 && threadIdx.x < kMaxCameras) {
         // the sample counts of this frame start at zero (k_prep_grid adds to them); the other parity's boxes are emptied
-        p.grid[kHdrCount + threadIdx.x] = 0;
+        p.boxes[kCountBase + threadIdx.x * kBoxStride] = 0;
         uint32_t *ob = p.boxes + ((p.parity ^ 1u) * kMaxCameras + threadIdx.x) * kBoxStride;
         ob[0] = 0xffffffffu; ob[1] = 0; ob[2] = 0xffffffffu; ob[3] = 0;
     }
@@ -1552,20 +1555,28 @@ __device__ __forceinline__ void span_any_all(const uint32_t *__restrict__ mb, ui
 
 constexpr uint32_t kEstPerThread = 4;
 
-__global__ __launch_bounds__(kBlock) void k_prep_grid(const CarveParams p, uint32_t *grid, const uint32_t *boxes, uint32_t parity,
-                                                      uint32_t min_shift, uint32_t budget_words, uint32_t nsamples)
+__global__ __launch_bounds__(kBlock) void k_prep_grid(const CarveParams p, uint32_t *grid, uint32_t *boxes_rw, uint32_t parity,
+                                                      uint32_t min_shift, uint32_t budget_words, uint32_t nsamples, uint32_t grid_wgs)
 {
-    const uint32_t y = blockIdx.y;
-    const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t *boxes = boxes_rw;
+    uint32_t *counts = boxes_rw + kCountBase;
+    __shared__ uint32_t s_hits[kMaxCameras];
+    if (threadIdx.x < kMaxCameras) s_hits[threadIdx.x] = 0;
+    __syncthreads();
+    // workgroups [0, grid_wgs): block grids -- the cameras' blocks one after the other (each camera rounded up to whole
+    // workgroups; all grids together hold at most 16 blocks per budgeted word); the rest: the sample counts
     const uint32_t lane = threadIdx.x & 63u;
-    if (y < p.C) {
+    if (blockIdx.x < grid_wgs) {
         // ---- the plan, by every wave for itself.  lane = candidate shift: words the grids of all cameras would take
         const uint32_t *box = boxes + parity * kMaxCameras * kBoxStride;
+        // lane c fetches camera c's box (one round trip for all cameras); everybody reads them across lanes
+        uint32_t mb0 = 0xffffffffu, mb1 = 0, mb2 = 0xffffffffu, mb3 = 0;
+        if (lane < p.C) { mb0 = box[kBoxStride * lane]; mb1 = box[kBoxStride * lane + 1]; mb2 = box[kBoxStride * lane + 2]; mb3 = box[kBoxStride * lane + 3]; }
         const uint32_t shift_c = lane < 15u ? lane : 14u;
         uint32_t total = kGridHeader;
         for (uint32_t c = 0; c < p.C; ++c) {
-            const uint32_t b0 = hdr_u32(box, kBoxStride * c), b1 = hdr_u32(box, kBoxStride * c + 1), b2 = hdr_u32(box, kBoxStride * c + 2),
-                           b3 = hdr_u32(box, kBoxStride * c + 3);
+            const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)mb0, (int)c), b1 = (uint32_t)__builtin_amdgcn_readlane((int)mb1, (int)c);
+            const uint32_t b2 = (uint32_t)__builtin_amdgcn_readlane((int)mb2, (int)c), b3 = (uint32_t)__builtin_amdgcn_readlane((int)mb3, (int)c);
             if (b0 > b1) continue;                                // no foreground in this camera
             total += 2u * (((b1 >> shift_c) >> 5) - ((b0 >> shift_c) >> 5) + 1u) * ((b3 >> shift_c) - (b2 >> shift_c) + 1u);
         }
@@ -1574,16 +1585,13 @@ __global__ __launch_bounds__(kBlock) void k_prep_grid(const CarveParams p, uint3
         const uint32_t shift = (uint32_t)__builtin_ctzll(fits);
         // lane = camera: its descriptor at the chosen shift, offsets by a scan over the cameras
         uint32_t w_lo = 0, v_lo = 0, cws = 0, ch = 0;
-        if (lane < p.C) {
-            const uint32_t b0 = box[kBoxStride * lane], b1 = box[kBoxStride * lane + 1], b2 = box[kBoxStride * lane + 2], b3 = box[kBoxStride * lane + 3];
-            if (b0 <= b1) {
-                w_lo = (b0 >> shift) >> 5; cws = ((b1 >> shift) >> 5) - w_lo + 1u;
-                v_lo = b2 >> shift; ch = (b3 >> shift) - v_lo + 1u;
-            }
+        if (lane < p.C && mb0 <= mb1) {
+            w_lo = (mb0 >> shift) >> 5; cws = ((mb1 >> shift) >> 5) - w_lo + 1u;
+            v_lo = mb2 >> shift; ch = (mb3 >> shift) - v_lo + 1u;
         }
         const uint32_t size = 2u * cws * ch;
         const uint32_t incl = wave_inclusive_scan(size, lane);
-        if (blockIdx.x == 0 && y == 0 && threadIdx.x < 64u) {    // one wave of the launch records the plan for the carve kernels
+        if (blockIdx.x == 0 && threadIdx.x < 64u) {              // one wave of the launch records the plan for the carve kernels
             if (lane < kMaxCameras) {
                 grid[3 * lane] = kGridHeader + incl - size;
                 grid[3 * lane + 1] = w_lo | (v_lo << 16);
@@ -1591,12 +1599,17 @@ __global__ __launch_bounds__(kBlock) void k_prep_grid(const CarveParams p, uint3
             }
             if (lane == 63) { grid[kHdrShift] = shift; grid[kHdrWords] = kGridHeader + incl; }
         }
+        // ---- which camera's blocks this workgroup classifies: prefix of the cameras' workgroup counts
+        const uint32_t cam_wgs = (32u * cws * ch + kBlock - 1) / kBlock;
+        const uint32_t wincl = wave_inclusive_scan(cam_wgs, lane);
+        const uint32_t y = (uint32_t)__popcll(__ballot(wincl <= blockIdx.x));          // cameras that end before this workgroup
+        if (y >= p.C) return;
+        const uint32_t t = (blockIdx.x - (uint32_t)__builtin_amdgcn_readlane((int)(wincl - cam_wgs), (int)y)) * kBlock + threadIdx.x;
         // ---- this workgroup's 256 blocks of camera y
         const uint32_t g_off = kGridHeader + (uint32_t)__builtin_amdgcn_readlane((int)(incl - size), (int)y);
         const uint32_t g_wlo = (uint32_t)__builtin_amdgcn_readlane((int)w_lo, (int)y), g_vlo = (uint32_t)__builtin_amdgcn_readlane((int)v_lo, (int)y);
         const uint32_t g_cws = (uint32_t)__builtin_amdgcn_readlane((int)cws, (int)y), g_ch = (uint32_t)__builtin_amdgcn_readlane((int)ch, (int)y);
         const uint32_t bw = g_cws * 32u, nb = bw * g_ch;          // block columns kept, blocks kept
-        if (blockIdx.x * kBlock >= nb) return;
         bool any = false, all = false;
         if (t < nb) {
             const uint32_t rv = t / bw, ru = t - rv * bw;
@@ -1607,7 +1620,21 @@ __global__ __launch_bounds__(kBlock) void k_prep_grid(const CarveParams p, uint3
                 const uint32_t y1 = ((bv + 1u) << shift) < p.H ? ((bv + 1u) << shift) : p.H;
                 const uint32_t *mb = p.maskbits + (size_t)y * p.mwords;
                 all = true;
-                for (uint32_t yy = y0; yy < y1; ++yy) span_any_all(mb, yy * p.W + x0, x1 - x0, any, all);
+                const uint32_t len = x1 - x0;
+                if (len <= 32u) {
+                    // a row of the block is a window of at most 32 bits: two words per row, the rows' loads independent of each other
+                    const uint32_t fullm = len == 32u ? 0xffffffffu : ((1u << len) - 1u);
+                    uint32_t acc_any = 0, acc_all = fullm;
+#pragma unroll 8
+                    for (uint32_t yy = y0; yy < y1; ++yy) {
+                        const uint32_t o = yy * p.W + x0, wi = o >> 5;
+                        const uint64_t two = ((uint64_t)mb[wi + 1 < p.mwords ? wi + 1 : wi] << 32) | mb[wi];
+                        const uint32_t win = (uint32_t)(two >> (o & 31u)) & fullm;
+                        acc_any |= win; acc_all &= win;
+                    }
+                    any = acc_any != 0; all = acc_all == fullm;
+                }
+                else for (uint32_t yy = y0; yy < y1; ++yy) span_any_all(mb, yy * p.W + x0, x1 - x0, any, all);
             }
         }
         // bw is a multiple of 32 and a wave starts at a multiple of 64: each half-wave is one grid word
@@ -1621,7 +1648,8 @@ __global__ __launch_bounds__(kBlock) void k_prep_grid(const CarveParams p, uint3
         return;
     }
     // ---- pass count of each camera on `nsamples` evenly spaced voxels of the slab, kEstPerThread per thread
-    if (blockIdx.x * kBlock * kEstPerThread >= nsamples) return;
+    const uint32_t eblock = blockIdx.x - grid_wgs;
+    if (eblock * kBlock * kEstPerThread >= nsamples) return;
     double X[kEstPerThread], Y[kEstPerThread], Z[kEstPerThread];
     uint32_t valid = 0;
 #pragma unroll
@@ -1644,8 +1672,10 @@ __global__ __launch_bounds__(kBlock) void k_prep_grid(const CarveParams p, uint3
             const bool hit = ((valid >> k) & 1u) && off >= 0 && mask_bit(p.maskbits + (size_t)c * p.mwords, off);
             hits += (uint32_t)__popcll(__ballot(hit));
         }
-        if (lane == 0 && hits) atomicAdd(&grid[kHdrCount + c], hits);
+        if (lane == 0 && hits) atomicAdd(&s_hits[c], hits);
     }
+    __syncthreads();
+    if (threadIdx.x < p.C && s_hits[threadIdx.x]) atomicAdd(&counts[threadIdx.x * kBoxStride], s_hits[threadIdx.x]);   // one line per camera
 }
 
 // ---------------------------------------------------------------- compaction

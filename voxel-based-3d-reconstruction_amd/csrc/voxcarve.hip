@@ -529,7 +529,7 @@ int ensure_prepared(vc_ctx *ctx, Slot &s, bool want_grids, const CarveParams *cp
             VC_HIP(ctx, hipMemsetAsync(s.grid.ptr, 0, s.grid.cap * sizeof(uint32_t), st));
         }
         if (!s.boxes.ptr) {
-            VC_TRY(ensure(ctx, s.boxes, (size_t)2 * kMaxCameras * kBoxStride));
+            VC_TRY(ensure(ctx, s.boxes, (size_t)3 * kMaxCameras * kBoxStride));
             std::vector<uint32_t> init(s.boxes.cap, 0u);                       // both box sets start empty
             for (uint32_t k = 0; k < 2 * kMaxCameras; ++k) { init[kBoxStride * k] = 0xffffffffu; init[kBoxStride * k + 2] = 0xffffffffu; }
             VC_HIP(ctx, hipMemcpyAsync(s.boxes.ptr, init.data(), init.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
@@ -588,12 +588,12 @@ int ensure_prepared(vc_ctx *ctx, Slot &s, bool want_grids, const CarveParams *cp
         const uint64_t n = p.n;
         const uint32_t ns = (uint32_t)(n < kEstimateSamples ? n : kEstimateSamples);
         const uint32_t est_wgs = ctx->reorder ? (ns + kBlock * kEstPerThread - 1) / (kBlock * kEstPerThread) : 0u;   // no counts: cameras in index order
-        if (!s.counts_zero) VC_HIP(ctx, hipMemsetAsync(s.grid.ptr + kHdrCount, 0, sizeof(uint32_t) * kMaxCameras, st));
+        if (!s.counts_zero) VC_HIP(ctx, hipMemsetAsync(s.boxes.ptr + kCountBase, 0, sizeof(uint32_t) * kMaxCameras * kBoxStride, st));
         s.counts_zero = false;
-        // a camera's grids hold at most 16 blocks per budgeted word
-        const uint32_t grid_wgs = (16u * s.budget_words + kBlock - 1) / kBlock;
-        hipLaunchKernelGGL(k_prep_grid, dim3(grid_wgs > est_wgs ? grid_wgs : est_wgs, C + (est_wgs ? 1 : 0)), dim3(kBlock), 0, st, p,
-                           s.grid.ptr, (const uint32_t *)s.boxes.ptr, s.parity, (uint32_t)ctx->grid_min_shift, s.budget_words, ns);
+        // all grids together hold at most 16 blocks per budgeted word; every camera's blocks are rounded up to whole workgroups
+        const uint32_t grid_wgs = (16u * s.budget_words + kBlock - 1) / kBlock + C;
+        hipLaunchKernelGGL(k_prep_grid, dim3(grid_wgs + est_wgs), dim3(kBlock), 0, st, p,
+                           s.grid.ptr, s.boxes.ptr, s.parity, (uint32_t)ctx->grid_min_shift, s.budget_words, ns, grid_wgs);
         VC_HIP(ctx, hipGetLastError());
         s.grids_valid = true;
     }
@@ -1331,6 +1331,7 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     if (s.prep_pending) { VC_HIP(ctx, hipStreamWaitEvent(ctx->stream, s.e_prep, 0)); s.prep_pending = false; }
     p.maskbits = s.bits.ptr;
     p.blockgrid = s.grid.ptr;
+    p.counts = s.boxes.ptr + kCountBase;
     // which table the step reads: the tile-ordered one (hierarchical kernels on tile words), else the y-major one
     const bool lut_tiled = mode == VC_MODE_LUT && fast && ctx->lut_hier && ctx->lut_tile && ctx->tile_valid;
     if (mode == VC_MODE_LUT && !lut_tiled) VC_TRY(ensure_ymajor(ctx));
