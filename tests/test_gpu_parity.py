@@ -1028,12 +1028,13 @@ def test_property_random_shapes_cameras_masks(eng):
     from hypothesis import given, settings, strategies as st, HealthCheck
     from oracle import carve_c
 
-    @settings(max_examples=40, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
-    @given(seed=st.integers(0, 10 ** 6), nx=st.integers(1, 6), ny=st.sampled_from([1, 7, 16, 63, 64, 65, 128, 192, 200]),
+    @settings(max_examples=60, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(seed=st.integers(0, 10 ** 6), nx=st.integers(1, 6), ny=st.sampled_from([1, 7, 16, 63, 64, 65, 128, 192, 200, 256, 256, 512]),
            nz=st.integers(1, 9), C=st.integers(1, 5), H=st.integers(8, 70), W=st.integers(8, 90),
            kind=st.sampled_from(["noise", "blob", "empty", "full", "sparse"]), below=st.booleans(), quad=st.booleans())
     def check(seed, nx, ny, nz, C, H, W, kind, below, quad):
-        nxx = nx * 4 if quad else nx                       # quad: nx % 4 == 0, so ny % 64 == 0 shapes take the tile kernels
+        # quad: nx % 4 == 0, so ny % 64 == 0 shapes take the tile kernels; ny = 256 / 512 with nx % 16 / 8 == 0 the brick pipeline
+        nxx = nx * (16 if ny == 256 else 8 if ny == 512 else 4) if quad else nx
         cams3, masks3, frames3 = fx.random_scene(seed, C=C, H=H, W=W, fg=0.5)
         rng = np.random.default_rng(seed)
         for m in masks3:
