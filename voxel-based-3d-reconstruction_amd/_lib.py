@@ -102,14 +102,15 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("VOXCARVE_LIB", LIB_PATH)          # an alternative build of the same library (sanitizer runs)
+    if not os.path.exists(path):
         raise VoxcarveError(
             "libvoxcarve.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
-            "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+            "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
     # multi-process GPU work on this platform needs dmabuf IPC (RCCL's hipIpcGetMemHandle fails otherwise);
     # must be in the environment before the HIP runtime initialises
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError = ABI drift, let it surface
         fn.restype = restype
