@@ -527,7 +527,7 @@ __device__ __forceinline__ void lut_refine_body(const CarveParams &p, uint32_t v
 #pragma unroll
                 for (int b = 0; b < B; ++b) {
                     mw[b] = (off[b] >= 0) ? mb[(uint32_t)off[b] >> 5] : (off[b] == -2 ? ~0u : 0u);
-                    mw2[b] = (off2[b] >= 0) ? mb2[(uint32_t)off2[b] >> 5] : (off2[b] == -2 ? ~0u : 0u);
+                    mw2[b] = !PAIR ? ~0u : (off2[b] >= 0) ? mb2[(uint32_t)off2[b] >> 5] : (off2[b] == -2 ? ~0u : 0u);
                 }
 #pragma unroll
                 for (int b = 0; b < B; ++b)
@@ -1094,6 +1094,7 @@ __global__ __launch_bounds__(kBlock) void k_cull(const CarveParams p)
 // shard can overflow.  A consumer wave scans the kShards counts once (lane = shard) and finds the shard of flat item t by
 // a ballot over the exclusive prefix.
 constexpr uint32_t kShards = 64;
+constexpr uint32_t kWideBlock = 1024;  // k_cull_bricks / k_brick_words run 256 or 1024 threads per workgroup (large grids: 16 waves share one LDS copy)
 constexpr uint32_t kShardStride = 32;   // u32 between two shard counters: one 128-byte line each (atomics on one LINE serialise too)
 struct BrickLists {
     uint32_t *counters;         // [2][3][kShards * kShardStride]: bricks, columns, words, of this parity; k_cull_bricks zeroes the other set
@@ -1135,14 +1136,14 @@ __device__ __forceinline__ void shard_locate(const ShardView &v, uint32_t t, uin
     size = (uint32_t)__builtin_amdgcn_readlane((int)v.size, (int)shard);
 }
 
-__global__ __launch_bounds__(kBlock) void k_cull_bricks(const CarveParams p, const BrickLists bl, uint32_t ngroups)
+__global__ __launch_bounds__(kWideBlock) void k_cull_bricks(const CarveParams p, const BrickLists bl, uint32_t ngroups)
 {
     extern __shared__ uint32_t s_grid[];
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(p.blockgrid);
         uint4 *dst = reinterpret_cast<uint4 *>(s_grid);
         const uint32_t gwords = hdr_u32(p.blockgrid, kHdrWords);
-        for (uint32_t i = threadIdx.x; i < (gwords + 3) / 4; i += kBlock) dst[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < (gwords + 3) / 4; i += blockDim.x) dst[i] = src[i];
         __syncthreads();
     }
     __shared__ uint32_t s_order[kMaxCameras];
@@ -1151,11 +1152,11 @@ __global__ __launch_bounds__(kBlock) void k_cull_bricks(const CarveParams p, con
     uint32_t *cnt = bl.counters + bl.parity * 3 * kShards * kShardStride;
     const uint32_t gshift = hdr_u32(s_grid, kHdrShift);
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
-    const uint32_t nwaves = gridDim.x * (kBlock / 64);
+    const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const uint32_t nwaves = gridDim.x * (blockDim.x / 64);
     const uint32_t nw = p.nbrick_pad >> 6;
     const uint32_t nbricks = p.nbx * p.tq * p.nbz;
-    for (uint32_t i = (blockIdx.x * kBlock + threadIdx.x); i < ngroups; i += gridDim.x * kBlock) p.groupcnt[i] = 0;
+    for (uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x); i < ngroups; i += gridDim.x * blockDim.x) p.groupcnt[i] = 0;
     for (uint32_t w = wave0; w < nw; w += nwaves) {
         const uint32_t b = w * 64 + lane;
         bool cand = b < nbricks, full = true;
@@ -1222,27 +1223,28 @@ __global__ __launch_bounds__(kBlock) void k_brick_boxes_bm(const CarveParams p, 
     }
 }
 
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_brick_words(const CarveParams p, const BrickLists bl)
+__global__ __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_brick_words(const CarveParams p, const BrickLists bl)
 {
     extern __shared__ uint32_t s_grid[];
     uint32_t *cnt = bl.counters + bl.parity * 3 * kShards * kShardStride;
     const ShardView sv = shard_view(cnt, 1, threadIdx.x & 63u);
     const uint32_t nlist = sv.total;
     if (blockIdx.x == 0 && threadIdx.x == 0) bl.host_counts[0] = nlist;
-    if (blockIdx.x * (kBlock / 64) >= nlist) return;              // fewer bricks than waves launched
-    {
+    if (blockIdx.x * (blockDim.x / 64) >= nlist) return;              // fewer bricks than waves launched
+    const bool passall = (p.dbg & 4u) != 0;                       // no word-level tests: every word of a listed brick goes to the voxel level
+    if (!passall) {
         const uint4 *src = reinterpret_cast<const uint4 *>(p.blockgrid);
         uint4 *dst = reinterpret_cast<uint4 *>(s_grid);
         const uint32_t gwords = hdr_u32(p.blockgrid, kHdrWords);
-        for (uint32_t i = threadIdx.x; i < (gwords + 3) / 4; i += kBlock) dst[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < (gwords + 3) / 4; i += blockDim.x) dst[i] = src[i];
         __syncthreads();
     }
     __shared__ uint32_t s_order[kMaxCameras];
     stage_order(p.counts, p.C, s_order);
-    const uint32_t gshift = hdr_u32(s_grid, kHdrShift);
+    const uint32_t gshift = passall ? 0u : hdr_u32(s_grid, kHdrShift);
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
-    const uint32_t nwaves = gridDim.x * (kBlock / 64);
+    const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const uint32_t nwaves = gridDim.x * (blockDim.x / 64);
     const uint32_t qpl = p.nx >> 2, nzl = (uint32_t)(p.n / ((uint64_t)p.nx * p.ny));
     for (uint32_t t = wave0; t < nlist; t += nwaves) {
         uint32_t shard, within, ssize;
@@ -1253,7 +1255,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         bool cand = qx < qpl && izl < nzl;
         uint32_t need = 0;                                        // by camera NUMBER (k_voxel_words has no use for the order)
         const size_t slot = (size_t)b * 64 + lane;
-        for (uint32_t q0 = 0; q0 < p.C && __ballot(cand) != 0 && !(p.dbg & 2u); q0 += 4) {
+        for (uint32_t q0 = 0; q0 < p.C && __ballot(cand) != 0 && !(p.dbg & 6u); q0 += 4) {
             uint64_t bb[4];
             uint32_t cn[4];
 #pragma unroll
@@ -1271,6 +1273,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             }
         }
         if (!cand) need = 0;
+        else if (passall) need = (1u << p.C) - 1u;
         const bool exists = qx < qpl && izl < nzl;
         const uint64_t T = ((uint64_t)(exists ? izl : 0u) * qpl + (exists ? qx : 0u)) * p.tq + by;
         if (exists && (need == 0 || (p.dbg & 1u))) bl.bm[T] = cand ? ~0ull : 0ull;     // decided here
@@ -1283,7 +1286,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 }
 
 // B undecided words per wave (list entries B t .. B t + B - 1), lanes = the 64 voxels of a tile word (4 x-rows x 16 y).
-template <bool LUT>
+template <bool LUT, bool PAIR = true>
 __global__ __launch_bounds__(kBlock) void k_voxel_words(const CarveParams p, const BrickLists bl)
 {
     constexpr int B = 8;
@@ -1318,7 +1321,7 @@ __global__ __launch_bounds__(kBlock) void k_voxel_words(const CarveParams p, con
                 const uint32_t c = (uint32_t)__builtin_ctz(left);
                 left &= left - 1;
                 uint32_t c2 = c;
-                if (left) { c2 = (uint32_t)__builtin_ctz(left); left &= left - 1; }
+                if (PAIR && left) { c2 = (uint32_t)__builtin_ctz(left); left &= left - 1; }
                 const int32_t *__restrict__ L1 = p.lut_tile + (size_t)c * p.n_pad + lane;
                 const int32_t *__restrict__ L2 = p.lut_tile + (size_t)c2 * p.n_pad + lane;
                 const uint32_t *__restrict__ mb = p.maskbits + (size_t)c * p.mwords;
@@ -1328,14 +1331,14 @@ __global__ __launch_bounds__(kBlock) void k_voxel_words(const CarveParams p, con
 #pragma unroll
                 for (int b = 0; b < B; ++b) {                     // a camera outside the word's mask counts as passed
                     const bool t1 = ((nd[b] >> c) & 1u) && ((alive >> b) & 1u);
-                    const bool t2 = c2 != c && ((nd[b] >> c2) & 1u) && ((alive >> b) & 1u);
+                    const bool t2 = PAIR && c2 != c && ((nd[b] >> c2) & 1u) && ((alive >> b) & 1u);
                     off[b] = t1 ? L1[(size_t)Tb[b] * 64] : -2;
                     off2[b] = t2 ? L2[(size_t)Tb[b] * 64] : -2;
                 }
 #pragma unroll
                 for (int b = 0; b < B; ++b) {
                     mw[b] = (off[b] >= 0) ? mb[(uint32_t)off[b] >> 5] : (off[b] == -2 ? ~0u : 0u);
-                    mw2[b] = (off2[b] >= 0) ? mb2[(uint32_t)off2[b] >> 5] : (off2[b] == -2 ? ~0u : 0u);
+                    mw2[b] = !PAIR ? ~0u : (off2[b] >= 0) ? mb2[(uint32_t)off2[b] >> 5] : (off2[b] == -2 ? ~0u : 0u);
                 }
 #pragma unroll
                 for (int b = 0; b < B; ++b)

@@ -217,6 +217,7 @@ struct vc_ctx {
     uint32_t list_parity = 0;
     int bricks = 1;                  // the brick pipeline where the grid shape allows (ny in {256, 512, 1024})
     int dbg = 0;
+    int voxel_pairs = 0;                     // k_voxel_words: 0 = by list length, 1 = two cameras per round, 2 = one
     bool kbox_valid = false;
     int cull = 1;                    // hierarchical kernels on tile words: cull whole bricks first
     bool tile_valid = false;
@@ -368,6 +369,7 @@ constexpr int kSub = 4;                    // 64-voxel sub-chunks per wavefront 
 constexpr size_t kLdsBytes = 160 * 1024;   // LDS per CU on gfx950
 constexpr size_t kMaxFirstLds = 64 * 1024; // static limit of one workgroup's dynamic LDS without opt-in
 constexpr uint32_t kEstimateSamples = 1u << 16;
+constexpr uint32_t kSingleCameraWords = 400000; // undecided words from which k_voxel_words reads one camera per round
 
 // The bricks' pixel boxes and the brick-major copy of the word boxes (once per grid / slab / camera set, right behind the
 // tile boxes).
@@ -441,19 +443,27 @@ int launch_bricks(vc_ctx *ctx, CarveParams &p, size_t lds, uint32_t ngroups)
     p.live = ctx->d_live.ptr;
     const volatile uint32_t *known = ctx->h_lists;                // lengths of an earlier step (any size is correct: the waves stride)
     const uint32_t k_bricks = known[0], k_cols = known[1], k_words = known[2];
-    const uint32_t cw = p.nbrick_pad / 256;
-    const dim3 block(kBlock);
-    // workgroups that stage the grids in LDS: no more than fit the chip at once when the grids are large (they stride over the lists)
+    // large grids (many cameras x large images): 16 waves share one LDS copy, so that the compute units stay full of waves
+    // with two or three workgroups each; no more workgroups than fit the chip at once (they stride over the lists)
+    const bool wide = lds > 20480;
+    const uint32_t wpg = wide ? kWideBlock / 64 : kBlock / 64;                // waves per workgroup
+    const dim3 block(kBlock), gblock(wpg * 64);
     const uint32_t fit = 256u * (uint32_t)(kLdsBytes / (lds ? lds : 1) < 1 ? 1 : kLdsBytes / (lds ? lds : 1));
-    const uint32_t lds_cap = lds > 20480 ? fit : 65536u;
+    const uint32_t lds_cap = wide ? fit : 65536u;
+    const uint32_t cw = nw / wpg;
     uint32_t cull_wgs = cw < 1 ? 1 : (cw > 1024 ? 1024 : cw);
     if (cull_wgs > lds_cap) cull_wgs = lds_cap;
-    uint32_t word_wgs = sized(k_bricks, p.nbrick_pad / 8, p.nbrick_pad, 4);
+    uint32_t word_wgs = sized(k_bricks, p.nbrick_pad / 8, p.nbrick_pad, wpg);
     if (word_wgs > lds_cap) word_wgs = lds_cap;
-    hipLaunchKernelGGL(k_cull_bricks, dim3(cull_wgs), block, lds, ctx->stream, p, bl, ngroups);
-    hipLaunchKernelGGL(k_brick_words, dim3(word_wgs), block, lds, ctx->stream, p, bl);
-    hipLaunchKernelGGL((k_voxel_words<LUT>), dim3(sized(k_words, (uint64_t)p.nbrick_pad * 4, (uint64_t)p.nbrick_pad * 64, 32)), block, 0,
-                       ctx->stream, p, bl);
+    hipLaunchKernelGGL(k_cull_bricks, dim3(cull_wgs), gblock, lds, ctx->stream, p, bl, ngroups);
+    if (p.dbg & 4u) hipLaunchKernelGGL(k_brick_words, dim3(sized(k_bricks, p.nbrick_pad / 8, p.nbrick_pad, 4)), block, 0, ctx->stream, p, bl);
+    else hipLaunchKernelGGL(k_brick_words, dim3(word_wgs), gblock, lds, ctx->stream, p, bl);
+    // long lists are bandwidth bound: one camera per dependent round (a second camera's entries are wasted on the voxels the
+    // first one rejects); short ones latency bound: two cameras per round
+    const bool pairs = !LUT || ctx->voxel_pairs == 1 || (ctx->voxel_pairs == 0 && (k_words == 0xffffffffu || k_words < kSingleCameraWords));
+    const dim3 vgrid(sized(k_words, (uint64_t)p.nbrick_pad * 4, (uint64_t)p.nbrick_pad * 64, 32));
+    if (pairs) hipLaunchKernelGGL((k_voxel_words<LUT, true>), vgrid, block, 0, ctx->stream, p, bl);
+    else hipLaunchKernelGGL((k_voxel_words<LUT, false>), vgrid, block, 0, ctx->stream, p, bl);
     hipLaunchKernelGGL(k_assemble, dim3(sized(k_cols == 0xffffffffu ? k_cols : k_cols * 16u, (uint64_t)ncolumns * 4, (uint64_t)ncolumns * 16, 4)),
                        block, 0, ctx->stream, p, bl);
     VC_HIP(ctx, hipGetLastError());
@@ -1781,6 +1791,7 @@ int vc_set_option(vc_ctx *ctx, const char *name, int value)
     else if (k == "cull") ctx->cull = value != 0;
     else if (k == "bricks") ctx->bricks = value != 0;
     else if (k == "dbg") ctx->dbg = value;
+    else if (k == "voxel_pairs") ctx->voxel_pairs = value;
     else if (k == "emit_busy" && value >= 0 && value <= 2) ctx->emit_busy = value;          // 0 never, 1 large grids, 2 always
     else if (k == "emit_waves_per_cu" && value >= 4 && value <= 1024) ctx->emit_waves_per_cu = value;
     else if (k == "lut_tile") ctx->lut_tile = value != 0;
