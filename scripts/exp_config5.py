@@ -25,6 +25,8 @@ for s in range(2):
 eng.build_lut()
 n = eng.carve(slot=0, mode=mode, color_cam=1)
 rec = eng.fetch_records()
+eng.debug_counters()
+n = eng.carve(slot=0, mode=mode, color_cam=1)
 print(eng.debug_counters(), flush=True)
 print("survivors %d digest %s" % (n, hashlib.sha256(np.ascontiguousarray(rec).tobytes()).hexdigest()[:16]), flush=True)
 def run(k):

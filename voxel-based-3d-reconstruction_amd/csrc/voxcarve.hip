@@ -217,7 +217,8 @@ struct vc_ctx {
     uint32_t list_parity = 0;
     int bricks = 1;                  // the brick pipeline where the grid shape allows (ny in {256, 512, 1024})
     int dbg = 0;
-    int voxel_pairs = 0;                     // k_voxel_words: 0 = by list length, 1 = two cameras per round, 2 = one
+    bool big_lds_ok = false;
+    int voxel_pairs = 0;                     // k_voxel_words: 0 = by camera count, 1 = two cameras per round, 2 = one
     bool kbox_valid = false;
     int cull = 1;                    // hierarchical kernels on tile words: cull whole bricks first
     bool tile_valid = false;
@@ -368,8 +369,8 @@ constexpr uint32_t kMaxScanBlocks = 1024;  // 2^32 voxels / 4096 per group / 102
 constexpr int kSub = 4;                    // 64-voxel sub-chunks per wavefront chunk (fused kernel)
 constexpr size_t kLdsBytes = 160 * 1024;   // LDS per CU on gfx950
 constexpr size_t kMaxFirstLds = 64 * 1024; // static limit of one workgroup's dynamic LDS without opt-in
+constexpr size_t kMaxWideLds = 152 * 1024; // what the brick pipeline's grid-staging kernels may take (one 1024-thread workgroup per CU)
 constexpr uint32_t kEstimateSamples = 1u << 16;
-constexpr uint32_t kSingleCameraWords = 400000; // undecided words from which k_voxel_words reads one camera per round
 
 // The bricks' pixel boxes and the brick-major copy of the word boxes (once per grid / slab / camera set, right behind the
 // tile boxes).
@@ -455,13 +456,17 @@ int launch_bricks(vc_ctx *ctx, CarveParams &p, size_t lds, uint32_t ngroups)
     if (cull_wgs > lds_cap) cull_wgs = lds_cap;
     uint32_t word_wgs = sized(k_bricks, p.nbrick_pad / 8, p.nbrick_pad, wpg);
     if (word_wgs > lds_cap) word_wgs = lds_cap;
+    if (lds > kMaxFirstLds && !ctx->big_lds_ok) {                             // more than 64 KB of dynamic LDS is opt-in
+        VC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cull_bricks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxWideLds));
+        VC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_brick_words), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxWideLds));
+        ctx->big_lds_ok = true;
+    }
     hipLaunchKernelGGL(k_cull_bricks, dim3(cull_wgs), gblock, lds, ctx->stream, p, bl, ngroups);
-    if (p.dbg & 4u) hipLaunchKernelGGL(k_brick_words, dim3(sized(k_bricks, p.nbrick_pad / 8, p.nbrick_pad, 4)), block, 0, ctx->stream, p, bl);
-    else hipLaunchKernelGGL(k_brick_words, dim3(word_wgs), gblock, lds, ctx->stream, p, bl);
-    // long lists are bandwidth bound: one camera per dependent round (a second camera's entries are wasted on the voxels the
-    // first one rejects); short ones latency bound: two cameras per round
-    const bool pairs = !LUT || ctx->voxel_pairs == 1 || (ctx->voxel_pairs == 0 && (k_words == 0xffffffffu || k_words < kSingleCameraWords));
-    const dim3 vgrid(sized(k_words, (uint64_t)p.nbrick_pad * 4, (uint64_t)p.nbrick_pad * 64, 32));
+    hipLaunchKernelGGL(k_brick_words, dim3(word_wgs), gblock, lds, ctx->stream, p, bl);
+    // many cameras: most voxels fail the first camera they ask, a second camera's entries read in the same round trip would be
+    // wasted on them; few cameras: two per dependent round (the lists are short, the kernel is latency bound)
+    const bool pairs = !LUT || ctx->voxel_pairs == 1 || (ctx->voxel_pairs == 0 && p.C <= 4);
+    const dim3 vgrid(sized(k_words, (uint64_t)p.nbrick_pad * 4, (uint64_t)p.nbrick_pad * 64, pairs ? 32 : 64));
     if (pairs) hipLaunchKernelGGL((k_voxel_words<LUT, true>), vgrid, block, 0, ctx->stream, p, bl);
     else hipLaunchKernelGGL((k_voxel_words<LUT, false>), vgrid, block, 0, ctx->stream, p, bl);
     hipLaunchKernelGGL(k_assemble, dim3(sized(k_cols == 0xffffffffu ? k_cols : k_cols * 16u, (uint64_t)ncolumns * 4, (uint64_t)ncolumns * 16, 4)),
@@ -504,11 +509,13 @@ uint32_t grid_for(uint64_t n);
 // whatever the slot's derived state is missing: bit masks + BGRX images + grid plan (k_prep_pack, after the optional 2x2
 // post-filter), and for the chunked / hierarchical kernels the block grids and the camera order (k_prep_grid).  No host
 // synchronisation: the kernels leave their results in the slot's header; e_prep marks their end for the carve stream.
-int ensure_prepared(vc_ctx *ctx, Slot &s, bool want_grids, const CarveParams *cp, bool timed = false)
+int ensure_prepared(vc_ctx *ctx, Slot &s, bool want_grids, const CarveParams *cp, bool timed = false, bool wide_ok = false)
 {
     const uint32_t C = ctx->C;
     const size_t HW = (size_t)ctx->H * ctx->W;
     hipStream_t st = ctx->stream_up;
+    // grids made for the brick pipeline's 1024-thread workgroups do not fit the other kernels' LDS: prepare again
+    if (want_grids && !wide_ok && s.bits_valid && (size_t)s.budget_words * sizeof(uint32_t) + 32 > kMaxFirstLds) s.bits_valid = s.grids_valid = false;
     if (s.bits_valid && !(want_grids && !s.grids_valid)) return VC_OK;
     // the kernels that still read what is about to be overwritten: carve kernels (bits, grids), record expansion (bits, images)
     if (s.carve_pending) { VC_HIP(ctx, hipStreamWaitEvent(st, s.e_carve, 0)); s.carve_pending = false; }
@@ -518,18 +525,22 @@ int ensure_prepared(vc_ctx *ctx, Slot &s, bool want_grids, const CarveParams *cp
     if (!s.bits_valid) {
         VC_TRY(ensure(ctx, s.bits, (size_t)ctx->mwords * C));
         // LDS budget of header + grids: 16 KB (eight workgroups per CU) unless the frame set is so large that 16 KB would
-        // force blocks of 32 x 32 pixels on it (16 cameras at 1080p); the kernels that stage the grids are launched with
-        // few, persistent workgroups in that case
+        // force blocks of 32 x 32 pixels on it (16 cameras at 1080p).  The kernels that stage the grids are then launched
+        // with few, persistent workgroups; the brick pipeline's run 1024 threads per workgroup, one or two per CU, so the
+        // grids may take most of a CU's LDS (blocks of 8 x 8 pixels for 16 cameras at 1080p: masks with salt noise leave
+        // 3 in 4 such blocks clean, 1 in 4 blocks of 16 x 16)
+        const uint32_t cap_words = (uint32_t)((wide_ok ? 148u : 64u) * 256u);
         uint32_t budget = (uint32_t)ctx->grid_lds_kb * 256u;                  // u32 words of header + grids
+        if (budget > cap_words) budget = cap_words;
         if (ctx->grid_lds_kb == 0) {
             budget = 16u * 256u;
             if ((uint64_t)ctx->mwords * C * 4 > (2u << 20)) {
-                // what the UNCROPPED grids of all cameras take at the finest block that keeps them within 64 KB: cropping can
+                // what the UNCROPPED grids of all cameras take at the finest block that keeps them within the cap: cropping can
                 // then only make the blocks finer, and the workgroups do not reserve more LDS than the grids can fill
                 for (uint32_t sh = (uint32_t)ctx->grid_min_shift; sh < 15; ++sh) {
                     const uint64_t bw = ((uint64_t)ctx->W + (1u << sh) - 1) >> sh, bh = ((uint64_t)ctx->H + (1u << sh) - 1) >> sh;
                     const uint64_t total = kGridHeader + (uint64_t)C * 2 * ((bw + 31) / 32) * bh;
-                    if (total <= 64u * 256u || sh == 14) { budget = (uint32_t)(total < 16u * 256u ? 16u * 256u : total); break; }
+                    if (total <= cap_words || sh == 14) { budget = (uint32_t)(total < 16u * 256u ? 16u * 256u : total); break; }
                 }
             }
         }
@@ -1337,7 +1348,11 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     sb.prepped = !s.bits_valid || (fast && !s.grids_valid);
     sb.carve_timed = ctx->timing_detail || ctx->sync_call;
     sb.prep_timed = sb.prepped && sb.carve_timed;
-    VC_TRY(ensure_prepared(ctx, s, fast, &p, sb.prep_timed));
+    // (the brick pipeline's grid-staging kernels take up to 148 KB of LDS, the others 64: the preparation sizes the grids for it)
+    const bool fused_tiles = mode == VC_MODE_FUSED && fast && ctx->ny % 64 == 0 && ctx->fused_hier && ctx->fused_tile && ctx->nx % 4 == 0 && ctx->fused_boxes;
+    if (fused_tiles) VC_TRY(ensure_boxes(ctx, true));
+    const bool bricks = fast && brick_shape(ctx, p) && (fused_tiles || (mode == VC_MODE_LUT && ctx->lut_hier && ctx->lut_tile && ctx->tile_valid));
+    VC_TRY(ensure_prepared(ctx, s, fast, &p, sb.prep_timed, bricks));
     if (s.prep_pending) { VC_HIP(ctx, hipStreamWaitEvent(ctx->stream, s.e_prep, 0)); s.prep_pending = false; }
     p.maskbits = s.bits.ptr;
     p.blockgrid = s.grid.ptr;
@@ -1795,7 +1810,7 @@ int vc_set_option(vc_ctx *ctx, const char *name, int value)
     else if (k == "emit_busy" && value >= 0 && value <= 2) ctx->emit_busy = value;          // 0 never, 1 large grids, 2 always
     else if (k == "emit_waves_per_cu" && value >= 4 && value <= 1024) ctx->emit_waves_per_cu = value;
     else if (k == "lut_tile") ctx->lut_tile = value != 0;
-    else if (k == "grid_lds_kb" && value >= 0 && value <= 64) ctx->grid_lds_kb = value;
+    else if (k == "grid_lds_kb" && value >= 0 && value <= 148) ctx->grid_lds_kb = value;
     else if (k == "grid_min_shift" && value >= 0 && value <= 8) ctx->grid_min_shift = value;
     else if (k == "fused_tile") ctx->fused_tile = value != 0;
     else if (k == "fused_f32box") ctx->fused_f32box = value != 0;
