@@ -1332,8 +1332,9 @@ __global__ __launch_bounds__(kBlock) void k_voxel_words(const CarveParams p, con
                 for (int b = 0; b < B; ++b) {                     // a camera outside the word's mask counts as passed
                     const bool t1 = ((nd[b] >> c) & 1u) && ((alive >> b) & 1u);
                     const bool t2 = PAIR && c2 != c && ((nd[b] >> c2) & 1u) && ((alive >> b) & 1u);
-                    off[b] = t1 ? L1[(size_t)Tb[b] * 64] : -2;
-                    off2[b] = t2 ? L2[(size_t)Tb[b] * 64] : -2;
+                    // (table entries are read once per step: streamed past the caches, which keep the mask bits)
+                    off[b] = t1 ? __builtin_nontemporal_load(&L1[(size_t)Tb[b] * 64]) : -2;
+                    off2[b] = t2 ? __builtin_nontemporal_load(&L2[(size_t)Tb[b] * 64]) : -2;
                 }
 #pragma unroll
                 for (int b = 0; b < B; ++b) {
@@ -1996,7 +1997,7 @@ __device__ __forceinline__ void emit_body(const EmitParams &p, uint32_t vblock)
 #pragma unroll
             for (int u = 0; u < EU; ++u) {
                 const uint64_t o = out0 + k0 + 64 * u + lane;
-                if (live[u] && o < p.capacity) p.records[o] = rec[u];
+                if (live[u] && o < p.capacity) __builtin_nontemporal_store(rec[u], &p.records[o]);
             }
         }
     }
@@ -2083,7 +2084,9 @@ __device__ __forceinline__ void emit_group_lanes(const EmitParams &p, const uint
         for (int b = 0; b < EB; ++b) {
             if ((wv[b] >> lane) & 1ull) {
                 const uint64_t o = out0 + ws[b] + (uint32_t)__popcll(wv[b] & below);
-                if (o < p.capacity) p.records[o] = rec[b];
+                // (streamed past the caches: 238 MB per step that nothing on the device reads again would evict the masks, images
+                // and block grids the next kernels want)
+                if (o < p.capacity) __builtin_nontemporal_store(rec[b], &p.records[o]);
             }
         }
     }
