@@ -13,8 +13,8 @@ Workloads (config.name):
            fixtures rolled by a few columns per frame set, synthetic colour frames.  N > 1: the grid is block-split
            along z (STRONG scaling, as BASELINE's ">= 6x at 8 GPUs" is stated).
   config5  BASELINE configs[4]: 512^3 x 16 synthetic ring cameras, 1080x1920 masks with 0.5 % salt noise, colour on.
-  big2048  2048 x 2048 x 1023 (4.29 G voxels, the u32 index limit) x the 4 real cameras, table-free mode: a case
-           for N > 1 where the carve kernels, not the record expansion, are most of a step.
+  big2048  2048 x 2048 x 1023 (4.29 G voxels, the u32 index limit) x the 4 real cameras, 68.7 GB of lookup tables on
+           one GPU (--mode fused: table-free): the largest case an index of 32 bits can address.
 
   python bench.py [--gpus N --steps K --warmup W] [--workload real|config5|big2048] [--grid 1024] [--mode lut|fused]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--workload", choices=("real", "config5", "big2048"), default="real")
     ap.add_argument("--grid", type=int, default=1024, help="workload real: N of the N^3 grid")
     ap.add_argument("--mode", choices=("lut", "lut_stream", "fused"), default=None,
-                    help="default: lut (real, config5), fused (big2048)")
+                    help="default: lut")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--prewarm-seconds", type=float, default=1.0,
@@ -151,8 +151,8 @@ def make_workload(args):
     cams, masks = fx.golden_cameras(), fx.golden_masks()
     frames = fx.synthetic_frames(len(cams), *masks[0].shape)
     if args.workload == "big2048":
-        return (2048, 2048, 1023), cams, masks, frames, 1, "fused", \
-            "2048x2048x1023 grid (u32 index limit) x the 4 real cameras, table-free"
+        return (2048, 2048, 1023), cams, masks, frames, 1, "lut", \
+            "2048x2048x1023 grid (u32 index limit) x the 4 real cameras (lookup tables: 68.7 GB)"
     G = args.grid
     return (G, G, G), cams, masks, frames, 1, "lut", "%d^3 voxel grid x the reference's 4 calibrated cameras" % G
 
@@ -345,7 +345,7 @@ def main():
         z0, z1 = bounds[grp.rank], bounds[grp.rank + 1]
         split_note = "balanced by measured chunk cost: z bounds %s" % bounds
     eng.set_slab(z0, z1)
-    have_lut = args.workload != "big2048" and not (args.mode == "fused" and args.only_headline)
+    have_lut = not (args.mode == "fused" and (args.only_headline or args.workload == "big2048"))
     if have_lut:
         eng.build_lut()
     eng.synchronize()

@@ -1,4 +1,4 @@
-"""Tuning aid: steady-state step time (two steps in flight, as bench.py runs them), 1024^3 x 4, options as k=v."""
+"""Tuning aid: steady-state step time (two steps in flight, as bench.py runs them), 1024^3 x 4 (or grid=nx,ny,nz), options as k=v."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -7,10 +7,16 @@ import voxcarve, fixtures_util as fx
 cams, masks = fx.golden_cameras(), fx.golden_masks()
 frames = fx.synthetic_frames(4, *masks[0].shape)
 eng = voxcarve.CarveEngine(0)
-eng.set_grid(1024, 1024, 1024); eng.set_cameras(cams, *masks[0].shape)
+grid = (1024, 1024, 1024)
+for opt in sys.argv[1:]:
+    if opt.startswith("grid="):
+        grid = tuple(int(x) for x in opt[5:].split(","))
+eng.set_grid(*grid); eng.set_cameras(cams, *masks[0].shape)
 mode = "lut"
 for opt in sys.argv[1:]:
     k, v = opt.split("=")
+    if k == "grid":
+        continue
     if k == "mode":
         mode = v
     else:
@@ -18,7 +24,8 @@ for opt in sys.argv[1:]:
 for s in range(4):
     eng.upload_masks([np.roll(m, 3 * s, axis=1) for m in masks], slot=s)
     eng.upload_frame(1, np.roll(frames[1], 3 * s, axis=1), slot=s)
-eng.build_lut()
+if mode == "lut":
+    eng.build_lut()
 def run(n):
     eng.carve_begin(slot=0, mode=mode)
     for i in range(1, n):

@@ -149,7 +149,7 @@ def test_random_scenes_ragged_shapes(eng, seed):
                     assert np.array_equal(eng.fetch_viewmask(), want["viewmask"])
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(10))
 def test_every_kernel_family_agrees_with_oracle(eng, seed):
     """The same scene through each carve implementation: hierarchical LUT on tile words (default where nx % 4 == 0 and
     ny % 64 == 0; grid 2 is the case whose waves do not coincide with y-major groups) and on y-line words, streaming LUT
@@ -157,8 +157,10 @@ def test_every_kernel_family_agrees_with_oracle(eng, seed):
     hierarchical kernels leave the words of dead groups unwritten and vc_fetch_occupancy has to fill them in."""
     from oracle import carve_c
     cams3, masks3, frames3 = fx.random_scene(100 + seed, C=4, H=60 + 7 * seed, W=80, fg=0.55)
-    # 4th: ny % 64 != 0; the last four are strip shapes (ny in {256, 512, 1024}), with partial bricks in x and z
-    grid = [(16, 128, 24), (40, 64, 9), (8, 192, 33), (5, 70, 19), (16, 256, 20), (8, 512, 9), (4, 1024, 3), (48, 256, 17)][seed]
+    # 4th: ny % 64 != 0; the last six are brick-pipeline shapes (ny in {256, 512, 1024, 2048, 4096}), with partial bricks in x and z;
+    # in the last two a brick column takes 2 / 4 rounds of 64 bricks and a row quad holds 2 / 4 groups
+    grid = [(16, 128, 24), (40, 64, 9), (8, 192, 33), (5, 70, 19), (16, 256, 20), (8, 512, 9), (4, 1024, 3), (48, 256, 17),
+            (12, 2048, 18), (20, 4096, 5)][seed]
     want = carve_c.carve(*grid, fx.oracle_cams(cams3), masks3, frames3, color_cam=2)
     assert want["count"] > 0
     eng.set_grid(*grid)
@@ -1029,11 +1031,11 @@ def test_property_random_shapes_cameras_masks(eng):
     from oracle import carve_c
 
     @settings(max_examples=60, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
-    @given(seed=st.integers(0, 10 ** 6), nx=st.integers(1, 6), ny=st.sampled_from([1, 7, 16, 63, 64, 65, 128, 192, 200, 256, 256, 512]),
+    @given(seed=st.integers(0, 10 ** 6), nx=st.integers(1, 6), ny=st.sampled_from([1, 7, 16, 63, 64, 65, 128, 192, 200, 256, 256, 512, 2048]),
            nz=st.integers(1, 9), C=st.integers(1, 5), H=st.integers(8, 70), W=st.integers(8, 90),
            kind=st.sampled_from(["noise", "blob", "empty", "full", "sparse"]), below=st.booleans(), quad=st.booleans())
     def check(seed, nx, ny, nz, C, H, W, kind, below, quad):
-        # quad: nx % 4 == 0, so ny % 64 == 0 shapes take the tile kernels; ny = 256 / 512 with nx % 16 / 8 == 0 the brick pipeline
+        # quad: nx % 4 == 0, so ny % 64 == 0 shapes take the tile kernels; ny = 256 / 512 with nx % 16 / 8 == 0 and ny = 2048 the brick pipeline
         nxx = nx * (16 if ny == 256 else 8 if ny == 512 else 4) if quad else nx
         cams3, masks3, frames3 = fx.random_scene(seed, C=C, H=H, W=W, fg=0.5)
         rng = np.random.default_rng(seed)

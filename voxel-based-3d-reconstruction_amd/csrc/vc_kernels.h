@@ -379,8 +379,22 @@ __device__ __forceinline__ void tile_store(const CarveParams &p, uint32_t g, uin
         const uint32_t izl = quad / qpl, qx = quad - izl * qpl;
         const uint64_t lw = (((uint64_t)izl * p.nx + qx * 4 + r) * p.ny + (uint64_t)ty * 16) >> 6;
         p.words[lw] = out;
-        const uint32_t pc = (uint32_t)__popcll(out);
-        if (!p.tile_whole && pc) atomicAdd(&p.groupcnt[lw >> 6], pc);
+        if (!p.tile_whole && (p.tq & 63u)) {                      // words of any group: one atomic per word with survivors
+            const uint32_t pc = (uint32_t)__popcll(out);
+            if (pc) atomicAdd(&p.groupcnt[lw >> 6], pc);
+        }
+    }
+    if (!p.tile_whole && !(p.tq & 63u)) {
+        // ny = 2048, 4096: the 16 words of row r are 1024 consecutive voxels of one group: one atomic per row
+        uint32_t pc = T < (p.n >> 6) ? (uint32_t)__popcll(out) : 0u;
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) pc += __shfl_xor(pc, d);
+        if (k == 0 && pc) {
+            const uint32_t quad = (uint32_t)(T / p.tq), ty = (uint32_t)(T - (uint64_t)quad * p.tq);
+            const uint32_t qpl = p.nx >> 2;
+            const uint32_t izl = quad / qpl, qx = quad - izl * qpl;
+            atomicAdd(&p.groupcnt[((((uint64_t)izl * p.nx + qx * 4 + r) * p.ny + (uint64_t)ty * 16) >> 6) >> 6], pc);
+        }
     }
     if (p.tile_whole) {
         uint32_t cnt = (uint32_t)__popcll(mine);
@@ -1157,40 +1171,48 @@ __global__ __launch_bounds__(kWideBlock) void k_cull_bricks(const CarveParams p,
     const uint32_t nw = p.nbrick_pad >> 6;
     const uint32_t nbricks = p.nbx * p.tq * p.nbz;
     for (uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x); i < ngroups; i += gridDim.x * blockDim.x) p.groupcnt[i] = 0;
-    for (uint32_t w = wave0; w < nw; w += nwaves) {
-        const uint32_t b = w * 64 + lane;
-        bool cand = b < nbricks, full = true;
-        for (uint32_t q0 = 0; q0 < p.C && __ballot(cand) != 0; q0 += 4) {
-            uint64_t bb[4];
+    // a wave takes 64 bricks at a time; a brick column has tq of them: 64 / tq whole columns per wave (ny <= 1024), or one column
+    // in tq / 64 rounds (ny = 2048, 4096), so that a column is listed once, by one wave
+    const uint32_t ipw = p.tq > 64u ? p.tq / 64u : 1u;
+    for (uint32_t W = wave0; W * ipw < nw; W += nwaves) {
+        uint64_t colany = 0;
+        for (uint32_t it = 0; it < ipw; ++it) {
+            const uint32_t w = W * ipw + it;
+            const uint32_t b = w * 64 + lane;
+            bool cand = b < nbricks, full = true;
+            for (uint32_t q0 = 0; q0 < p.C && __ballot(cand) != 0; q0 += 4) {
+                uint64_t bb[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                bb[k] = (q0 + k < p.C && cand) ? p.kbox[(size_t)ord(s_order, q0 + k) * p.nbrick_pad + b] : 0ull;
+                for (int k = 0; k < 4; ++k)
+                    bb[k] = (q0 + k < p.C && cand) ? p.kbox[(size_t)ord(s_order, q0 + k) * p.nbrick_pad + b] : 0ull;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (q0 + k < p.C && cand) {
-                    const uint32_t r = box_test(s_grid, load_gridcam(s_grid, ord(s_order, q0 + k)), bb[k], gshift);
-                    cand = r != 0;
-                    full = full && r == 2;
+                for (int k = 0; k < 4; ++k) {
+                    if (q0 + k < p.C && cand) {
+                        const uint32_t r = box_test(s_grid, load_gridcam(s_grid, ord(s_order, q0 + k)), bb[k], gshift);
+                        cand = r != 0;
+                        full = full && r == 2;
+                    }
                 }
             }
+            const uint64_t lw = __ballot(cand), fw = __ballot(cand && full);
+            p.live[w] = lw;                                       // (all lanes, same value: one store)
+            p.live[nw + w] = fw;
+            colany |= lw;
+            // bricks to look into
+            const uint64_t bm = lw & ~fw;
+            if (bm) {
+                const uint32_t at = shard_append(cnt, bl.cap_b, W % kShards, bm, lane);
+                if ((bm >> lane) & 1ull) bl.bricks[at] = b;
+            }
         }
-        const uint64_t lw = __ballot(cand), fw = __ballot(cand && full);
-        p.live[w] = lw;                                           // (all lanes, same value: one store)
-        p.live[nw + w] = fw;
-        if (lw == 0) continue;                                    // (wave-uniform)
-        // bricks to look into
-        const uint64_t bm = lw & ~fw;
-        if (bm) {
-            const uint32_t at = shard_append(cnt, bl.cap_b, w % kShards, bm, lane);
-            if ((bm >> lane) & 1ull) bl.bricks[at] = b;
-        }
-        // columns with a live brick: tq divides 64, so a wave holds 64 / tq whole columns; lane j < 64 / tq speaks for column j
-        const uint32_t ncol = 64u / p.tq;
-        const uint64_t colbits = p.tq == 64 ? lw : (lw >> ((lane < ncol ? lane : 0u) * p.tq)) & ((1ull << p.tq) - 1ull);
+        if (colany == 0) continue;                                // (wave-uniform)
+        // columns with a live brick; lane j < 64 / tq speaks for column j of the wave (lane 0 for the only one)
+        const uint32_t ncol = p.tq > 64u ? 1u : 64u / p.tq;
+        const uint64_t colbits = p.tq >= 64u ? colany : (colany >> ((lane < ncol ? lane : 0u) * p.tq)) & ((1ull << p.tq) - 1ull);
         const bool cwant = lane < ncol && colbits != 0;
         const uint64_t cm = __ballot(cwant);
-        const uint32_t cat = shard_append(cnt + kShards * kShardStride, bl.cap_c, w % kShards, cm, lane);
-        if (cwant) bl.columns[cat] = (w * 64) / p.tq + lane;
+        const uint32_t cat = shard_append(cnt + kShards * kShardStride, bl.cap_c, W % kShards, cm, lane);
+        if (cwant) bl.columns[cat] = p.tq > 64u ? W : (W * 64) / p.tq + lane;
     }
 }
 
@@ -1387,10 +1409,43 @@ __global__ __launch_bounds__(kBlock) void k_assemble(const CarveParams p, const 
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
     const uint32_t nwaves = gridDim.x * (kBlock / 64);
     const uint32_t qpl = p.nx >> 2, nzl = (uint32_t)(p.n / ((uint64_t)p.nx * p.ny));
-    const uint32_t qpg = 64u / p.tq;                              // row quads per group (1, 2 or 4)
-    const uint32_t gq = 4u / qpg;                                 // groups along x inside a brick column (4, 2 or 1)
     const uint32_t nunits = ncols * 16u;
     const uint32_t nw = p.nbrick_pad >> 6;
+    if (p.tq > 64u) {
+        // ny = 2048, 4096: a row quad holds tq / 64 wave loads of tile words and 2 or 4 groups (of 2 rows or 1); every word of
+        // the column's layer is stored, the groups' counts are added up with atomics (tile_store, tile_whole == 0)
+        const uint32_t parts = p.tq / 64u;
+        for (uint32_t u = wave0; u < nunits; u += nwaves) {
+            const uint32_t ci = u >> 4, l = u & 15u;              // wave-uniform
+            uint32_t shard, within, ssize;
+            shard_locate(sv, ci, shard, within, ssize);
+            const uint32_t col = hdr_u32(bl.columns, shard * bl.cap_c + within);
+            const uint32_t bz = col / p.nbx, bx = col - bz * p.nbx;
+            const uint32_t izl = 16 * bz + l;
+            if (izl >= nzl) continue;
+            for (uint32_t h = 0; h < parts; ++h) {
+                const uint32_t b = col * p.tq + 64u * h + lane;   // my brick (the same for the four row quads)
+                const uint64_t lw = p.live[b >> 6], fw = p.live[nw + (b >> 6)];
+                const bool live = (lw >> (b & 63u)) & 1ull, full = (fw >> (b & 63u)) & 1ull;
+                uint64_t mine[4];
+#pragma unroll
+                for (uint32_t q = 0; q < 4; ++q) {
+                    const uint64_t gw = ((uint64_t)izl * qpl + 4 * bx + q) * p.tq + 64u * h;
+                    mine[q] = (4 * bx + q < qpl && live) ? (full ? ~0ull : bl.bm[gw + lane]) : 0ull;
+                }
+#pragma unroll
+                for (uint32_t q = 0; q < 4; ++q) {
+                    if (4 * bx + q < qpl) {
+                        const uint64_t gw = ((uint64_t)izl * qpl + 4 * bx + q) * p.tq + 64u * h;
+                        tile_store(p, 0u, gw, lane, mine[q]);
+                    }
+                }
+            }
+        }
+        return;
+    }
+    const uint32_t qpg = 64u / p.tq;                              // row quads per group (1, 2 or 4)
+    const uint32_t gq = 4u / qpg;                                 // groups along x inside a brick column (4, 2 or 1)
     const uint32_t dq = lane / p.tq, ty = lane - dq * p.tq;       // my tile word inside a group: row quad dq, tile column ty
     for (uint32_t u = wave0; u < nunits; u += nwaves) {
         const uint32_t ci = u >> 4, l = u & 15u;                  // wave-uniform

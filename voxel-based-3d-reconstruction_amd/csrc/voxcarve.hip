@@ -396,8 +396,8 @@ int build_brick_boxes(vc_ctx *ctx)
 bool brick_shape(const vc_ctx *ctx, const CarveParams &p)
 {
     if (!ctx->bricks || !ctx->cull || !ctx->kbox_valid) return false;
-    if (ctx->ny != 256 && ctx->ny != 512 && ctx->ny != 1024) return false;
-    if (ctx->nx % (4096u / ctx->ny) != 0 || ctx->nx % 4 != 0) return false;
+    if (ctx->ny != 256 && ctx->ny != 512 && ctx->ny != 1024 && ctx->ny != 2048 && ctx->ny != 4096) return false;
+    if (ctx->nx % 4 != 0 || (ctx->ny < 1024 && ctx->nx % (4096u / ctx->ny) != 0)) return false;
     return true;
 }
 
@@ -415,10 +415,11 @@ template <bool LUT>
 int launch_bricks(vc_ctx *ctx, CarveParams &p, size_t lds, uint32_t ngroups)
 {
     const uint32_t ncolumns = p.nbx * p.nbz;
-    const uint32_t nw = p.nbrick_pad / 64;                                    // waves of k_cull_bricks
+    const uint32_t ipw = p.tq > 64 ? p.tq / 64 : 1;                           // rounds of 64 bricks per wave of k_cull_bricks (a whole column)
+    const uint32_t nw = p.nbrick_pad / 64 / ipw;                              // waves of k_cull_bricks
     const uint32_t wps = (nw + kShards - 1) / kShards;                        // producers per shard
     BrickLists bl;
-    bl.cap_b = wps * 64; bl.cap_c = wps * 4;
+    bl.cap_b = wps * 64 * ipw; bl.cap_c = wps * 4;
     bl.cap_w = (p.nbrick_pad + kShards - 1) / kShards * 64;                   // a listed brick appends at most its 64 words
     VC_TRY(ensure(ctx, ctx->d_bm, (size_t)(p.n_pad / 64)));
     VC_TRY(ensure(ctx, ctx->d_wlist, (size_t)bl.cap_w * kShards));
