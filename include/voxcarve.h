@@ -190,7 +190,7 @@ int vc_fetch_mesh(vc_ctx *ctx, float *verts, uint32_t *faces);
  * (tests/test_gpu_parity.py runs every family against the oracle).  Defaults are the measured best on MI355X.
  *   kernel choice   lut_hier (1)  hierarchical lookup-table kernel, 0 = stream the table (k_lut_first + refine)
  *                   lut_tile, fused_tile (1)  words of 4 x-rows x 16 y where nx % 4 == 0 and ny % 64 == 0
- *                   bricks (1)  ny in {256, 512, 1024}: the brick pipeline (whole 16^3-voxel bricks decided from their pixel
+ *                   bricks (1)  ny in {256, 512, 1024, 2048, 4096}: the brick pipeline (whole 16^3-voxel bricks decided from their pixel
  *                                  boxes, flat lists of bricks / undecided words / columns, one launch per level) instead of
  *                                  the one-launch hierarchical kernels
  *                   cull (1)  the one-launch kernels on tile words skip whole bricks too (k_cull); 0 also switches `bricks` off
@@ -199,10 +199,14 @@ int vc_fetch_mesh(vc_ctx *ctx, float *verts, uint32_t *faces);
  *                   fused_color_table (0)  table-free carve, survivors coloured from the colour camera's table (4 B per
  *                                  voxel of the whole grid, one camera) instead of by projecting each of them again
  *                   refine_pair (1), reorder (1)  two cameras per round trip; most selective camera first
+ *                   voxel_pairs (0)  per-voxel level of the brick pipeline: 0 = two cameras per round trip up to 4 cameras, one
+ *                                  above; 1 = always two; 2 = always one
  *                   emit_lanes (1), emit_busy (1: grids >= 64 M voxels, 2: always, 0: never)  record expansion form
  *                   force_generic (0)  one thread per voxel everywhere (also env VOXCARVE_FORCE_GENERIC=1)
- *   frame sets      grid_lds_kb (0 = 16, or 64 for frame sets above 2 MB of mask bits), grid_min_shift (1)  LDS budget / finest
- *                                  block of the cropped block grids (read when a frame set is next prepared)
+ *   frame sets      grid_lds_kb (0 = 16; frame sets above 2 MB of mask bits: what their uncropped grids need at the finest block
+ *                                  that fits 148 KB, brick pipeline, or 64 KB, other kernels; explicit values above 64 are
+ *                                  clamped to 64 for those), grid_min_shift (1)  LDS budget / finest block of the cropped
+ *                                  block grids (read when a frame set is next prepared)
  *   launch shape    hier_blocks_per_cu (48), emit_waves_per_cu (256), first_kv (1), first_blocks_per_cu (3),
  *                   refine_b (8), refine_blocks_per_cu (8), fused_blocks_per_cu (8)
  *   streams         overlap (1)  scan + record expansion of a step on a second stream, beside the next step's carve
