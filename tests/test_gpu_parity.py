@@ -278,16 +278,22 @@ def test_config5_full_size_512_cubed_16_cameras_1080p(eng):
     eng.upload_frame(1, sframes[1])
     eng.build_lut()
     digest = None
-    for mode in ("lut", "fused"):
-        for lds in (16, 64):                                  # block grids of 32 px and of 16 px
-            eng.set_option("grid_lds_kb", lds)
-            eng.touch_masks(0)
-            assert eng.carve(mode=mode, color_cam=1) == want["count"], (mode, lds)
-            rec = eng.fetch_records()
-            idx, rgb, seen = voxcarve_unpack(rec)
-            assert np.array_equal(idx, want["idx"]) and np.array_equal(rgb[:, ::-1], want["bgr"]) and seen.all(), (mode, lds)
-            digest = hashlib.sha256(rec.tobytes()).hexdigest()
-    eng.set_option("grid_lds_kb", 0)
+    try:
+        for mode in ("lut", "fused"):
+            # block grids of 32, 16 and 8 px (the last: 138 KB of LDS shared by 1024-thread workgroups, the default for this frame
+            # set); the per-voxel level asking one camera per round (default above 4 cameras) and two
+            for lds, pairs in ((16, 0), (64, 0), (148, 0), (148, 1), (0, 2)):
+                eng.set_option("grid_lds_kb", lds)
+                eng.set_option("voxel_pairs", pairs)
+                eng.touch_masks(0)
+                assert eng.carve(mode=mode, color_cam=1) == want["count"], (mode, lds, pairs)
+                rec = eng.fetch_records()
+                idx, rgb, seen = voxcarve_unpack(rec)
+                assert np.array_equal(idx, want["idx"]) and np.array_equal(rgb[:, ::-1], want["bgr"]) and seen.all(), (mode, lds, pairs)
+                digest = hashlib.sha256(rec.tobytes()).hexdigest()
+    finally:
+        eng.set_option("voxel_pairs", 0)
+        eng.set_option("grid_lds_kb", 0)
     eng.touch_masks(0)
     ents = []
     for r in range(8):
@@ -298,6 +304,33 @@ def test_config5_full_size_512_cubed_16_cameras_1080p(eng):
     assert eng.expand_entries(slabs.merge_rank_entries(ents)) == want["count"]
     assert hashlib.sha256(eng.fetch_gathered().tobytes()).hexdigest() == digest
     eng.set_slab(0, 512)
+
+
+def test_config3_synthetic_set_1024_cubed(eng):
+    """SURVEY 8(d) config 3 with its SYNTHETIC mask set (the config-5 generator at 486 x 644, 4 ring cameras, ellipsoid
+    silhouettes XOR 0.5 % salt noise) at full size, both modes, every record against the full C oracle; the real-mask case
+    of config 3 is bench.py's default workload and test_full_size_1024_properties."""
+    from voxcarve import synthetic
+    from oracle import carve_c
+    if len(os.sched_getaffinity(0)) < 16:
+        pytest.skip("the full-grid oracle needs a many-core host")
+    H, W, C = 486, 644, 4
+    scams = synthetic.ring_cameras(C, H, W)
+    smasks = synthetic.ellipsoid_masks(scams, H, W)
+    sframes = synthetic.random_frames(C, H, W)
+    grid = (1024, 1024, 1024)
+    want = carve_c.carve(*grid, fx.oracle_cams(scams), smasks, sframes, color_cam=1, cap=1 << 27)
+    assert want["count"] > 10 ** 5
+    eng.set_grid(*grid)
+    eng.set_cameras(scams, H, W)
+    eng.upload_masks(smasks)
+    eng.upload_frame(1, sframes[1])
+    eng.build_lut()
+    for mode in ("lut", "fused"):
+        assert eng.carve(mode=mode, color_cam=1) == want["count"], mode
+        idx, rgb, seen = voxcarve_unpack(eng.fetch_records())
+        assert np.array_equal(idx, want["idx"]) and np.array_equal(rgb[:, ::-1], want["bgr"]) and seen.all(), mode
+    eng.set_grid(8, 8, 8)                                     # give the 17 GB of tables back
 
 
 def test_config5_shape_16_cameras_1080p(eng):
