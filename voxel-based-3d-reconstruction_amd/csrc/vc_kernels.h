@@ -9,8 +9,10 @@
 //
 //   per frame set   k_morph2x2 (optional), k_prep_pack, k_prep_grid: two launches, nothing returns to the host
 //   per geometry    k_build_lut<TILE> (table and/or word boxes), k_brick_boxes_bm
-//   carve           k_lut_refine<B,HIER,PAIR,TILE>   hierarchical lookup-table kernel (default VC_MODE_LUT)
-//                   k_carve_fused_hier<TILE,BOX>     the same with the projection in-kernel (default VC_MODE_FUSED)
+//   carve           k_cull_bricks, k_brick_words, k_voxel_words<LUT,PAIR>, k_assemble   the brick pipeline (default for
+//                                                    ny in {256, 512, 1024, 2048, 4096}; see its section below)
+//                   k_lut_refine<B,HIER,PAIR,TILE>   one-launch hierarchical lookup-table kernel (other shapes, VC_MODE_LUT)
+//                   k_carve_fused_hier<TILE,BOX>     the same with the projection in-kernel (other shapes, VC_MODE_FUSED)
 //                   k_lut_first + k_lut_refine<.,false,.>   the table streamed without skipping (roofline_stream)
 //                   k_carve_fused<KSUB,NY64>, k_carve_generic<LUT,VM>   chunked / one thread per voxel (any shape,
 //                                                                     thresholds below C, camera bit masks)
@@ -1082,7 +1084,7 @@ __global__ __launch_bounds__(kBlock) void k_cull(const CarveParams p)
 }
 
 // ---------------------------------------------------------------- brick pipeline
-// The default carve for ny in {256, 512, 1024} (groups of 4096 consecutive voxels then lie inside one brick column).
+// The default carve for ny in {256, 512, 1024, 2048, 4096} (groups of 4096 consecutive voxels then lie inside one brick column).
 // Culling whole bricks leaves a wave of the group-wise kernels with a handful of live lanes (the hull crosses a line of
 // 1024 voxels along y in a few bricks only), and what is left is latency: a wave walks through entry -> boxes -> table ->
 // mask, one dependent round trip after the other, for a few words.  So the work is re-cut by what it needs, one
@@ -1095,7 +1097,8 @@ __global__ __launch_bounds__(kBlock) void k_cull(const CarveParams p)
 //                  a brick-major copy (512 contiguous bytes per camera).  Decided words (dead / all alive) are stored to the
 //                  brick-major word buffer; undecided ones go to the WORD LIST with the cameras that still have to look.
 //  k_voxel_words   one wave per 8 listed words, lanes = the 64 voxels of a word: table entry (LUT) or float64 projection,
-//                  mask bit, for the listed cameras, two cameras per dependent round trip.  No block grids: no LDS to fill.
+//                  mask bit, for the listed cameras, two cameras per dependent round trip (PAIR; one above 4 cameras).  No
+//                  block grids: no LDS to fill.  Table entries are loaded non-temporally (read once per step).
 //  k_assemble      one wave per group of the listed columns: collects the group's 64 tile words (dead brick: 0, full
 //                  brick: all ones, else the brick-major buffer), turns them into y-major words (tile_store) and stores
 //                  words + count.  Groups of unlisted columns keep count 0 and nobody reads their words.
