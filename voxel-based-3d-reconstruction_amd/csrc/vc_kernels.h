@@ -88,6 +88,28 @@ __device__ __forceinline__ GridCam load_gridcam(const uint32_t *grids, uint32_t 
     return {a, (uint16_t)b, (uint16_t)(b >> 16), (uint16_t)d, (uint16_t)(d >> 16)};
 }
 
+// Header + grids of a frame set into LDS: 16 bytes per lane, four loads in flight per lane (a plain copy loop is compiled
+// to load, wait, store per round: one memory round trip per 16 bytes and lane).  Ends with a barrier.
+__device__ __forceinline__ void stage_grids(uint32_t *s_grid, const uint32_t *__restrict__ blockgrid)
+{
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    const v4u *__restrict__ src = reinterpret_cast<const v4u *>(blockgrid);
+    v4u *dst = reinterpret_cast<v4u *>(s_grid);
+    const uint32_t n = ((uint32_t)__builtin_amdgcn_readfirstlane((int)blockgrid[kHdrWords]) + 3u) / 4u;      // (buffer padded to 16 B)
+    const uint32_t bd = blockDim.x;
+    for (uint32_t i = threadIdx.x; i < n; i += 4 * bd) {
+        v4u v0 = src[i], v1 = src[i + bd < n ? i + bd : n - 1u], v2 = src[i + 2 * bd < n ? i + 2 * bd : n - 1u],
+            v3 = src[i + 3 * bd < n ? i + 3 * bd : n - 1u];           // (clamped: no select behind a load)
+        // (keeps the four loads together, ahead of the conditional stores: the compiler would sink each into its store's branch)
+        asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));
+        dst[i] = v0;
+        if (i + bd < n) dst[i + bd] = v1;
+        if (i + 2 * bd < n) dst[i + 2 * bd] = v2;
+        if (i + 3 * bd < n) dst[i + 3 * bd] = v3;
+    }
+    __syncthreads();
+}
+
 struct CarveParams {
     const double *xs, *ys, *zs;
     const uint32_t *maskbits;   // [C][mwords] of the active frame set
@@ -433,13 +455,7 @@ __device__ __forceinline__ void brick_bits(const CarveParams &p, uint64_t T, boo
 template <int B, bool HIER, bool PAIR, bool TILE = false>
 __device__ __forceinline__ void lut_refine_body(const CarveParams &p, uint32_t vblock, uint32_t nblocks, uint32_t *s_grid)
 {
-    if (HIER) {                                                   // header + grids into LDS, 16 bytes per lane (buffer padded to 16 B)
-        const uint4 *src = reinterpret_cast<const uint4 *>(p.blockgrid);
-        uint4 *dst = reinterpret_cast<uint4 *>(s_grid);
-        const uint32_t gwords = hdr_u32(p.blockgrid, kHdrWords);
-        for (uint32_t i = threadIdx.x; i < (gwords + 3) / 4; i += kBlock) dst[i] = src[i];
-        __syncthreads();
-    }
+    if (HIER) stage_grids(s_grid, p.blockgrid);
     __shared__ uint32_t s_order[kMaxCameras];
     stage_order(p.counts, p.C, s_order);       // camera order (and block size) of this frame set
     const uint32_t gshift = HIER ? hdr_u32(s_grid, kHdrShift) : 0u;
@@ -801,13 +817,7 @@ template <bool TILE, int BOX>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_carve_fused_hier(const CarveParams p)
 {
     extern __shared__ uint32_t s_grid[];                          // the cropped block grids of all cameras
-    {
-        const uint4 *src = reinterpret_cast<const uint4 *>(p.blockgrid);
-        uint4 *dst = reinterpret_cast<uint4 *>(s_grid);
-        const uint32_t gwords = hdr_u32(p.blockgrid, kHdrWords);
-        for (uint32_t i = threadIdx.x; i < (gwords + 3) / 4; i += kBlock) dst[i] = src[i];
-        __syncthreads();
-    }
+    stage_grids(s_grid, p.blockgrid);
     __shared__ uint32_t s_order[kMaxCameras];
     stage_order(p.counts, p.C, s_order);
     const uint32_t gshift = hdr_u32(s_grid, kHdrShift);
@@ -1047,13 +1057,7 @@ __global__ __launch_bounds__(kBlock) void k_project(const CamDev cam, const doub
 __global__ __launch_bounds__(kBlock) void k_cull(const CarveParams p)
 {
     extern __shared__ uint32_t s_grid[];
-    {
-        const uint4 *src = reinterpret_cast<const uint4 *>(p.blockgrid);
-        uint4 *dst = reinterpret_cast<uint4 *>(s_grid);
-        const uint32_t gwords = hdr_u32(p.blockgrid, kHdrWords);
-        for (uint32_t i = threadIdx.x; i < (gwords + 3) / 4; i += kBlock) dst[i] = src[i];
-        __syncthreads();
-    }
+    stage_grids(s_grid, p.blockgrid);
     __shared__ uint32_t s_order[kMaxCameras];
     stage_order(p.counts, p.C, s_order);
     const uint32_t gshift = hdr_u32(s_grid, kHdrShift);
@@ -1156,13 +1160,7 @@ __device__ __forceinline__ void shard_locate(const ShardView &v, uint32_t t, uin
 __global__ __launch_bounds__(kWideBlock) void k_cull_bricks(const CarveParams p, const BrickLists bl, uint32_t ngroups)
 {
     extern __shared__ uint32_t s_grid[];
-    {
-        const uint4 *src = reinterpret_cast<const uint4 *>(p.blockgrid);
-        uint4 *dst = reinterpret_cast<uint4 *>(s_grid);
-        const uint32_t gwords = hdr_u32(p.blockgrid, kHdrWords);
-        for (uint32_t i = threadIdx.x; i < (gwords + 3) / 4; i += blockDim.x) dst[i] = src[i];
-        __syncthreads();
-    }
+    stage_grids(s_grid, p.blockgrid);
     __shared__ uint32_t s_order[kMaxCameras];
     stage_order(p.counts, p.C, s_order);
     if (blockIdx.x == 0 && threadIdx.x < 3 * kShards) bl.counters[((bl.parity ^ 1u) * 3 * kShards + threadIdx.x) * kShardStride] = 0;
@@ -1256,14 +1254,8 @@ __global__ __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu(8, 8
     const uint32_t nlist = sv.total;
     if (blockIdx.x == 0 && threadIdx.x == 0) bl.host_counts[0] = nlist;
     if (blockIdx.x * (blockDim.x / 64) >= nlist) return;              // fewer bricks than waves launched
-    const bool passall = (p.dbg & 4u) != 0;                       // no word-level tests: every word of a listed brick goes to the voxel level
-    if (!passall) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(p.blockgrid);
-        uint4 *dst = reinterpret_cast<uint4 *>(s_grid);
-        const uint32_t gwords = hdr_u32(p.blockgrid, kHdrWords);
-        for (uint32_t i = threadIdx.x; i < (gwords + 3) / 4; i += blockDim.x) dst[i] = src[i];
-        __syncthreads();
-    }
+    const bool passall = (p.dbg & 4u) != 0;                       // experiment: no word-level tests, every word of a listed brick goes to the voxel level
+    stage_grids(s_grid, p.blockgrid);
     __shared__ uint32_t s_order[kMaxCameras];
     stage_order(p.counts, p.C, s_order);
     const uint32_t gshift = passall ? 0u : hdr_u32(s_grid, kHdrShift);
@@ -2072,81 +2064,135 @@ __global__ __launch_bounds__(kBlock) void k_emit_words(const EmitParams p)
 // sparse words (the hull's words are dense: ~44 of 64 bits).  EB words are expanded together.
 // INDIRECT: the "words" are gathered {bits, base} entries of all ranks (p.n = 64 x entries, p.lut =
 // the colour camera's table over the WHOLE grid, p.z0 = p.i0 = 0): voxel index = base + lane.
-template <bool FROM_LUT, bool ALLSEEN, int EB, bool INDIRECT>
-__device__ __forceinline__ void emit_group_lanes(const EmitParams &p, const uint32_t g, const uint32_t lane)
+// One batch of EB words of a group in flight: what is wave-uniform about each word (scalar registers) and each lane's table
+// entry / pixel offset for its voxel of that word.
+template <int EB>
+struct EmitBatch {
+    uint32_t ws[EB], jb[EB];
+    uint64_t wv[EB];
+    int32_t off[EB];
+    bool any;
+};
+
+// takes the next (up to) EB non-zero words of the group off `nz` and starts their table loads (or projects)
+template <bool FROM_LUT, int EB, bool INDIRECT>
+__device__ __forceinline__ void emit_prepare(const EmitParams &p, uint64_t &nz, uint64_t mine, uint32_t mybase, uint32_t wstart,
+                                             uint32_t tbase, uint64_t gw, uint32_t lane, EmitBatch<EB> &B)
 {
+    B.any = nz != 0;
+    uint32_t tb[EB];
+#pragma unroll
+    for (int b = 0; b < EB; ++b) {
+        B.wv[b] = 0; B.ws[b] = 0; B.jb[b] = 0; tb[b] = 0;
+        if (nz != 0) {
+            const uint32_t li = (uint32_t)__builtin_ctzll(nz);
+            nz &= nz - 1;
+            B.jb[b] = INDIRECT ? (uint32_t)__builtin_amdgcn_readlane((int)mybase, (int)li) : (uint32_t)((gw + li) << 6);
+            const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, (int)li);
+            const uint32_t whi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), (int)li);
+            B.wv[b] = ((uint64_t)whi << 32) | wlo;
+            B.ws[b] = (uint32_t)__builtin_amdgcn_readlane((int)wstart, (int)li);
+            tb[b] = (uint32_t)__builtin_amdgcn_readlane((int)tbase, (int)li);
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < EB; ++b) {
+        B.off[b] = -1;
+        if (p.has_cam && ((B.wv[b] >> lane) & 1ull)) {
+            const uint32_t j = B.jb[b] + lane;
+            if (FROM_LUT) {
+                // (tile order: jb is a multiple of 64 and ny % 64 == 0, so the word's 64 voxels are 4 runs of 16 entries;
+                // everything but the lane terms is wave-uniform)
+                B.off[b] = p.lut[(!INDIRECT && p.lut_tq) ? tb[b] + ((lane >> 4) << 6) + (lane & 15u) : j];
+            } else {
+                uint32_t ix, iy, izl;
+                decompose(j, p.nx, p.ny, ix, iy, izl);
+                double u, v;
+                project_point(p.cam, p.xs[ix], p.ys[iy], p.zs[p.z0 + izl], u, v);
+                B.off[b] = pixel_offset(u, v, p.H, p.W);
+            }
+        }
+    }
+}
+
+// colour gathers and record stores of a prepared batch
+template <bool ALLSEEN, int EB>
+__device__ __forceinline__ void emit_finish(const EmitParams &p, uint64_t out0, uint32_t lane, const EmitBatch<EB> &B)
+{
+    const uint64_t below = (1ull << lane) - 1ull;
+    // all gathers of the batch are issued before any of them is used (a load consumed inside its own branch is waited for
+    // inside it: eight round trips in a row)
+    uint32_t mw[EB], px[EB];
+#pragma unroll
+    for (int b = 0; b < EB; ++b) {
+        mw[b] = ~0u;
+        if (!ALLSEEN && p.maskbits && B.off[b] >= 0) mw[b] = p.maskbits[(uint32_t)B.off[b] >> 5];
+    }
+    bool seen[EB];
+#pragma unroll
+    for (int b = 0; b < EB; ++b) {
+        seen[b] = B.off[b] >= 0 && (ALLSEEN || (p.maskbits && ((mw[b] >> ((uint32_t)B.off[b] & 31u)) & 1u)));
+        px[b] = 0u;
+        if (seen[b] && p.frame) px[b] = p.frame[B.off[b]];                          // B | G<<8 | R<<16
+    }
+    uint64_t rec[EB];
+#pragma unroll
+    for (int b = 0; b < EB; ++b) {
+        rec[b] = (uint32_t)(p.i0 + B.jb[b] + lane);
+        if (seen[b])
+            rec[b] |= (uint64_t)((px[b] >> 16) & 0xffu) << 32 | (uint64_t)((px[b] >> 8) & 0xffu) << 40 | (uint64_t)(px[b] & 0xffu) << 48 | (1ull << 56);
+    }
+#pragma unroll
+    for (int b = 0; b < EB; ++b) {
+        if ((B.wv[b] >> lane) & 1ull) {
+            const uint64_t o = out0 + B.ws[b] + (uint32_t)__popcll(B.wv[b] & below);
+            // (streamed past the caches: 238 MB per step that nothing on the device reads again would evict the masks, images
+            // and block grids the next kernels want)
+            if (o < p.capacity) __builtin_nontemporal_store(rec[b], &p.records[o]);
+        }
+    }
+}
+
+// What a wave needs of a group before it can start: its 64 words (one per lane) and where its records begin.
+struct EmitGroup {
+    uint64_t mine, out0;
+    uint32_t mybase;
+};
+template <bool INDIRECT>
+__device__ __forceinline__ EmitGroup emit_load_group(const EmitParams &p, uint32_t g, uint32_t lane)
+{
+    EmitGroup h;
     const uint64_t nwords = (p.n + 63) >> 6;
-    const uint64_t out0 = p.blockoff[g / kScanBlock] + p.groupoff[g];
+    h.out0 = p.blockoff[g / kScanBlock] + p.groupoff[g];
     const uint64_t gw = (uint64_t)g * kGroupWords;
-    uint64_t mine = 0ull;
-    uint32_t mybase = 0;
+    h.mine = 0ull;
+    h.mybase = 0;
     if (gw + lane < nwords) {
         if (INDIRECT) {
             const ulonglong2 e = reinterpret_cast<const ulonglong2 *>(p.entries)[gw + lane];
-            mine = e.x; mybase = (uint32_t)e.y;
-        } else mine = p.words[gw + lane];
+            h.mine = e.x; h.mybase = (uint32_t)e.y;
+        } else h.mine = p.words[gw + lane];
     }
-    const uint32_t c = (uint32_t)__popcll(mine);
+    return h;
+}
+
+// The dependent chain of a batch is table entry -> pixel -> store; the next batch's table loads are issued before the
+// current batch's pixels are waited for, so a group of B batches costs about B + 1 round trips instead of 2 B.
+template <bool FROM_LUT, bool ALLSEEN, int EB, bool INDIRECT>
+__device__ __forceinline__ void emit_group_lanes(const EmitParams &p, const uint32_t g, const uint32_t lane, const EmitGroup &h)
+{
+    const uint64_t gw = (uint64_t)g * kGroupWords;
+    const uint32_t c = (uint32_t)__popcll(h.mine);
     const uint32_t wstart = wave_inclusive_scan(c, lane) - c;           // first record of my word in the group
     // colour look-up in a TILE-ordered table: where my word's 64 entries start (4 runs of 16; all lanes at once, once per group)
     const uint32_t tbase = (FROM_LUT && !INDIRECT && p.lut_tq) ? tile_index((uint32_t)((gw + lane) << 6), p.nx, p.ny, p.lut_tq) : 0u;
-    const uint64_t below = (1ull << lane) - 1ull;
-    uint64_t nz = __ballot(mine != 0);
-    while (nz != 0) {                                                   // wave-uniform
-        uint32_t li[EB], ws[EB], jb[EB], tb[EB];
-        uint64_t wv[EB];
-#pragma unroll
-        for (int b = 0; b < EB; ++b) {
-            li[b] = 0; wv[b] = 0; ws[b] = 0; jb[b] = 0; tb[b] = 0;
-            if (nz != 0) {
-                li[b] = (uint32_t)__builtin_ctzll(nz);
-                nz &= nz - 1;
-                jb[b] = INDIRECT ? (uint32_t)__builtin_amdgcn_readlane((int)mybase, (int)li[b])
-                                 : (uint32_t)((gw + li[b]) << 6);
-                const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, (int)li[b]);
-                const uint32_t whi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), (int)li[b]);
-                wv[b] = ((uint64_t)whi << 32) | wlo;
-                ws[b] = (uint32_t)__builtin_amdgcn_readlane((int)wstart, (int)li[b]);
-                tb[b] = (uint32_t)__builtin_amdgcn_readlane((int)tbase, (int)li[b]);
-            }
-        }
-        int32_t off[EB];
-#pragma unroll
-        for (int b = 0; b < EB; ++b) {
-            off[b] = -1;
-            if (p.has_cam && ((wv[b] >> lane) & 1ull)) {
-                const uint32_t j = jb[b] + lane;
-                if (FROM_LUT) {
-                    // (tile order: jb is a multiple of 64 and ny % 64 == 0, so the word's 64 voxels are 4 runs of 16 entries;
-                    // everything but the lane terms is wave-uniform)
-                    off[b] = p.lut[(!INDIRECT && p.lut_tq) ? tb[b] + ((lane >> 4) << 6) + (lane & 15u) : j];
-                } else {
-                    uint32_t ix, iy, izl;
-                    decompose(j, p.nx, p.ny, ix, iy, izl);
-                    double u, v;
-                    project_point(p.cam, p.xs[ix], p.ys[iy], p.zs[p.z0 + izl], u, v);
-                    off[b] = pixel_offset(u, v, p.H, p.W);
-                }
-            }
-        }
-        uint64_t rec[EB];
-#pragma unroll
-        for (int b = 0; b < EB; ++b) {
-            rec[b] = (uint32_t)(p.i0 + jb[b] + lane);
-            if (off[b] >= 0 && (ALLSEEN || (p.maskbits && mask_bit(p.maskbits, off[b])))) {
-                const uint64_t px = p.frame ? (uint64_t)p.frame[off[b]] : 0ull;           // B | G<<8 | R<<16
-                rec[b] |= ((px >> 16) & 0xffull) << 32 | ((px >> 8) & 0xffull) << 40 | (px & 0xffull) << 48 | (1ull << 56);
-            }
-        }
-#pragma unroll
-        for (int b = 0; b < EB; ++b) {
-            if ((wv[b] >> lane) & 1ull) {
-                const uint64_t o = out0 + ws[b] + (uint32_t)__popcll(wv[b] & below);
-                // (streamed past the caches: 238 MB per step that nothing on the device reads again would evict the masks, images
-                // and block grids the next kernels want)
-                if (o < p.capacity) __builtin_nontemporal_store(rec[b], &p.records[o]);
-            }
-        }
+    uint64_t nz = __ballot(h.mine != 0);
+    EmitBatch<EB> A, B;
+    emit_prepare<FROM_LUT, EB, INDIRECT>(p, nz, h.mine, h.mybase, wstart, tbase, gw, lane, A);
+    while (A.any) {                                                     // wave-uniform
+        emit_prepare<FROM_LUT, EB, INDIRECT>(p, nz, h.mine, h.mybase, wstart, tbase, gw, lane, B);
+        emit_finish<ALLSEEN, EB>(p, h.out0, lane, A);
+        A = B;
     }
 }
 
@@ -2157,11 +2203,12 @@ __global__ __launch_bounds__(kBlock) void k_emit_lanes(const EmitParams p)
     const uint32_t g = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
     if (g >= p.ngroups) return;
     if (p.groupcnt[g] == 0) return;
-    emit_group_lanes<FROM_LUT, ALLSEEN, EB, INDIRECT>(p, g, lane);
+    emit_group_lanes<FROM_LUT, ALLSEEN, EB, INDIRECT>(p, g, lane, emit_load_group<INDIRECT>(p, g, lane));
 }
 
 // The same expansion driven by the list of busy groups (k_finish_scan): a fixed grid of waves strides over
-// it, so no wave is launched only to find its group empty (5 of 6 are).
+// it, so no wave is launched only to find its group empty (5 of 6 are).  A wave loads its next group's words and
+// offsets before it works on the current one (and that group's number one step earlier still).
 template <bool FROM_LUT, bool ALLSEEN, int EB>
 __global__ __launch_bounds__(kBlock) void k_emit_busy(const EmitParams p)
 {
@@ -2169,8 +2216,18 @@ __global__ __launch_bounds__(kBlock) void k_emit_busy(const EmitParams p)
     const uint32_t w = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
     const uint32_t nwaves = gridDim.x * (kBlock / 64);
     const uint32_t nbusy = p.busycount[0];
-    for (uint32_t t = w; t < nbusy; t += nwaves)
-        emit_group_lanes<FROM_LUT, ALLSEEN, EB, false>(p, p.busylist[t], lane);
+    if (w >= nbusy) return;
+    uint32_t g = p.busylist[w];
+    uint32_t g1 = w + nwaves < nbusy ? p.busylist[w + nwaves] : 0u;
+    EmitGroup h = emit_load_group<false>(p, g, lane);
+    for (uint32_t t = w; t < nbusy; t += nwaves) {
+        const bool more = t + nwaves < nbusy;                          // (wave-uniform)
+        const uint32_t g2 = t + 2 * nwaves < nbusy ? p.busylist[t + 2 * nwaves] : 0u;
+        EmitGroup hn = h;
+        if (more) hn = emit_load_group<false>(p, g1, lane);
+        emit_group_lanes<FROM_LUT, ALLSEEN, EB, false>(p, g, lane, h);
+        h = hn; g = g1; g1 = g2;
+    }
 }
 
 }  // namespace vc
