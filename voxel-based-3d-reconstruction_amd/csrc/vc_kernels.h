@@ -380,11 +380,24 @@ __device__ __forceinline__ uint32_t box_test(const uint32_t *__restrict__ grids,
     return (miss == 0 && (bb & kBoxAllInside)) ? 2u : 1u;
 }
 
+// Sum over the 64 lanes with data-parallel-primitive moves (no trip through the LDS crossbar: six ds_bpermute in a row cost
+// ~700 cycles of latency); every lane gets the total.
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8: lane 15 of each row holds the row's sum
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // Result of a wave that worked on tile words (lane = tile word gw + lane, 4 x-rows x 16 y each): lane (r, k)
 // assembles the y-major word of row r, y chunk k from tile words 4k .. 4k+3 (16 bits each) and stores it.
 // tile_whole: the wave's words are exactly y-major group g, its count is stored; otherwise the counts
 // are accumulated with atomics into a zeroed groupcnt.
-__device__ __forceinline__ void tile_store(const CarveParams &p, uint32_t g, uint64_t gw, uint32_t lane, uint64_t mine)
+__device__ __forceinline__ uint64_t tile_transpose(uint64_t mine, uint32_t lane)
 {
     const uint32_t r = lane >> 4, k = lane & 15u;
     uint64_t out = 0;
@@ -396,12 +409,23 @@ __device__ __forceinline__ void tile_store(const CarveParams &p, uint32_t g, uin
         const uint64_t m = ((uint64_t)hi << 32) | lo;
         out |= ((m >> (16 * r)) & 0xffffull) << (16 * q);
     }
+    return out;
+}
+// y-major word index of row r of the row quad of tile word T, at T's y (T = first of the four tile words of a y-major word)
+__device__ __forceinline__ uint64_t tile_word_index(const CarveParams &p, uint64_t T, uint32_t r)
+{
+    const uint32_t quad = (uint32_t)(T / p.tq), ty = (uint32_t)(T - (uint64_t)quad * p.tq);
+    const uint32_t qpl = p.nx >> 2;                               // row quads per layer
+    const uint32_t izl = quad / qpl, qx = quad - izl * qpl;
+    return (((uint64_t)izl * p.nx + qx * 4 + r) * p.ny + (uint64_t)ty * 16) >> 6;
+}
+__device__ __forceinline__ void tile_store(const CarveParams &p, uint32_t g, uint64_t gw, uint32_t lane, uint64_t mine)
+{
+    const uint32_t r = lane >> 4, k = lane & 15u;
+    const uint64_t out = tile_transpose(mine, lane);
     const uint64_t T = gw + 4 * k;                                // first of the four tile words
     if (T < (p.n >> 6)) {
-        const uint32_t quad = (uint32_t)(T / p.tq), ty = (uint32_t)(T - (uint64_t)quad * p.tq);
-        const uint32_t qpl = p.nx >> 2;                           // row quads per layer
-        const uint32_t izl = quad / qpl, qx = quad - izl * qpl;
-        const uint64_t lw = (((uint64_t)izl * p.nx + qx * 4 + r) * p.ny + (uint64_t)ty * 16) >> 6;
+        const uint64_t lw = tile_word_index(p, T, r);
         p.words[lw] = out;
         if (!p.tile_whole && (p.tq & 63u)) {                      // words of any group: one atomic per word with survivors
             const uint32_t pc = (uint32_t)__popcll(out);
@@ -413,17 +437,10 @@ __device__ __forceinline__ void tile_store(const CarveParams &p, uint32_t g, uin
         uint32_t pc = T < (p.n >> 6) ? (uint32_t)__popcll(out) : 0u;
 #pragma unroll
         for (int d = 8; d >= 1; d >>= 1) pc += __shfl_xor(pc, d);
-        if (k == 0 && pc) {
-            const uint32_t quad = (uint32_t)(T / p.tq), ty = (uint32_t)(T - (uint64_t)quad * p.tq);
-            const uint32_t qpl = p.nx >> 2;
-            const uint32_t izl = quad / qpl, qx = quad - izl * qpl;
-            atomicAdd(&p.groupcnt[((((uint64_t)izl * p.nx + qx * 4 + r) * p.ny + (uint64_t)ty * 16) >> 6) >> 6], pc);
-        }
+        if (k == 0 && pc) atomicAdd(&p.groupcnt[tile_word_index(p, T, r) >> 6], pc);
     }
     if (p.tile_whole) {
-        uint32_t cnt = (uint32_t)__popcll(mine);
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
+        const uint32_t cnt = wave_sum_u32((uint32_t)__popcll(mine));
         if (lane == 0) p.groupcnt[g] = cnt;
     }
 }
@@ -1441,7 +1458,8 @@ __global__ __launch_bounds__(kBlock) void k_assemble(const CarveParams p, const 
     }
     const uint32_t qpg = 64u / p.tq;                              // row quads per group (1, 2 or 4)
     const uint32_t gq = 4u / qpg;                                 // groups along x inside a brick column (4, 2 or 1)
-    const uint32_t dq = lane / p.tq, ty = lane - dq * p.tq;       // my tile word inside a group: row quad dq, tile column ty
+    const uint32_t tqs = (uint32_t)__builtin_ctz(p.tq);           // (tq = 16, 32 or 64)
+    const uint32_t dq = lane >> tqs, ty = lane & (p.tq - 1u);     // my tile word inside a group: row quad dq, tile column ty
     for (uint32_t u = wave0; u < nunits; u += nwaves) {
         const uint32_t ci = u >> 4, l = u & 15u;                  // wave-uniform
         uint32_t shard, within, ssize;
@@ -1460,12 +1478,26 @@ __global__ __launch_bounds__(kBlock) void k_assemble(const CarveParams p, const 
             const uint64_t gw = ((uint64_t)izl * qpl + qx0) * p.tq;
             mine[xg] = (xg < gq && qx0 + dq < qpl && live) ? (full ? ~0ull : bl.bm[gw + lane]) : 0ull;
         }
+        // (tq divides 64 here: the wave's 64 tile words ARE group gw / 64.  All four groups are transposed and counted before
+        // anything is stored: a store between two transposes makes the compiler wait for it)
+        uint64_t out[4];
+        uint32_t cnt[4];
+#pragma unroll
+        for (uint32_t xg = 0; xg < 4; ++xg) {
+            out[xg] = tile_transpose(mine[xg], lane);
+            cnt[xg] = wave_sum_u32((uint32_t)__popcll(mine[xg]));
+        }
 #pragma unroll
         for (uint32_t xg = 0; xg < 4; ++xg) {
             const uint32_t qx0 = 4 * bx + xg * qpg;
             if (xg < gq && qx0 < qpl) {
                 const uint64_t gw = ((uint64_t)izl * qpl + qx0) * p.tq;   // first tile word of the group = 64 x its group number
-                tile_store(p, (uint32_t)(gw >> 6), gw, lane, mine[xg]);
+                // lane (r, k) holds row r, y chunk k of the group: tile words 4 k .. 4 k + 3 = row quad qx0 + 4 k / tq, tile column
+                // 4 k % tq (tq is a power of two here)
+                const uint32_t k4 = 4u * (lane & 15u), dqk = k4 >> tqs, tyk = k4 & (p.tq - 1u);
+                if (qx0 + dqk < qpl)
+                    p.words[(((uint64_t)izl * p.nx + (qx0 + dqk) * 4 + (lane >> 4)) * p.ny + (uint64_t)tyk * 16) >> 6] = out[xg];
+                if (lane == 0) p.groupcnt[gw >> 6] = cnt[xg];
             }
         }
     }
