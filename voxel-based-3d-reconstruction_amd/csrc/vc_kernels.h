@@ -962,13 +962,17 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
     return v;
 }
 
+// Inclusive prefix sum over the 64 lanes (all of them active), with data-parallel-primitive moves: row-wise Hillis-Steele, then
+// the totals of the rows before (the same steps as wave_sum_u32; six ds_bpermute in a row would cost ~700 cycles of latency).
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane)
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(v, d);
-        if (lane >= (uint32_t)d) v += o;
-    }
+    (void)lane;
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
     return v;
 }
 
