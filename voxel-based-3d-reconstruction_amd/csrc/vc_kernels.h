@@ -2104,7 +2104,8 @@ __global__ __launch_bounds__(kBlock) void k_emit_words(const EmitParams p)
 // entry / pixel offset for its voxel of that word.
 template <int EB>
 struct EmitBatch {
-    uint32_t ws[EB], jb[EB];
+    uint32_t wl[EB];            // first record of the word inside the group (<= 4096) | word number inside the group << 16
+    uint32_t jb[EB];            // INDIRECT only: voxel index of the word's bit 0 (else it follows from the word number)
     uint64_t wv[EB];
     int32_t off[EB];
     bool any;
@@ -2119,15 +2120,15 @@ __device__ __forceinline__ void emit_prepare(const EmitParams &p, uint64_t &nz, 
     uint32_t tb[EB];
 #pragma unroll
     for (int b = 0; b < EB; ++b) {
-        B.wv[b] = 0; B.ws[b] = 0; B.jb[b] = 0; tb[b] = 0;
+        B.wv[b] = 0; B.wl[b] = 0; B.jb[b] = 0; tb[b] = 0;
         if (nz != 0) {
             const uint32_t li = (uint32_t)__builtin_ctzll(nz);
             nz &= nz - 1;
-            B.jb[b] = INDIRECT ? (uint32_t)__builtin_amdgcn_readlane((int)mybase, (int)li) : (uint32_t)((gw + li) << 6);
+            if (INDIRECT) B.jb[b] = (uint32_t)__builtin_amdgcn_readlane((int)mybase, (int)li);
             const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, (int)li);
             const uint32_t whi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), (int)li);
             B.wv[b] = ((uint64_t)whi << 32) | wlo;
-            B.ws[b] = (uint32_t)__builtin_amdgcn_readlane((int)wstart, (int)li);
+            B.wl[b] = (uint32_t)__builtin_amdgcn_readlane((int)wstart, (int)li) | (li << 16);
             tb[b] = (uint32_t)__builtin_amdgcn_readlane((int)tbase, (int)li);
         }
     }
@@ -2135,9 +2136,9 @@ __device__ __forceinline__ void emit_prepare(const EmitParams &p, uint64_t &nz, 
     for (int b = 0; b < EB; ++b) {
         B.off[b] = -1;
         if (p.has_cam && ((B.wv[b] >> lane) & 1ull)) {
-            const uint32_t j = B.jb[b] + lane;
+            const uint32_t j = (INDIRECT ? B.jb[b] : (uint32_t)((gw + (B.wl[b] >> 16)) << 6)) + lane;
             if (FROM_LUT) {
-                // (tile order: jb is a multiple of 64 and ny % 64 == 0, so the word's 64 voxels are 4 runs of 16 entries;
+                // (tile order: the word starts at a multiple of 64 and ny % 64 == 0, so its 64 voxels are 4 runs of 16 entries;
                 // everything but the lane terms is wave-uniform)
                 B.off[b] = p.lut[(!INDIRECT && p.lut_tq) ? tb[b] + ((lane >> 4) << 6) + (lane & 15u) : j];
             } else {
@@ -2152,8 +2153,8 @@ __device__ __forceinline__ void emit_prepare(const EmitParams &p, uint64_t &nz, 
 }
 
 // colour gathers and record stores of a prepared batch
-template <bool ALLSEEN, int EB>
-__device__ __forceinline__ void emit_finish(const EmitParams &p, uint64_t out0, uint32_t lane, const EmitBatch<EB> &B)
+template <bool ALLSEEN, int EB, bool INDIRECT>
+__device__ __forceinline__ void emit_finish(const EmitParams &p, uint64_t out0, uint64_t gw, uint32_t lane, const EmitBatch<EB> &B)
 {
     const uint64_t below = (1ull << lane) - 1ull;
     // all gathers of the batch are issued before any of them is used (a load consumed inside its own branch is waited for
@@ -2174,14 +2175,14 @@ __device__ __forceinline__ void emit_finish(const EmitParams &p, uint64_t out0, 
     uint64_t rec[EB];
 #pragma unroll
     for (int b = 0; b < EB; ++b) {
-        rec[b] = (uint32_t)(p.i0 + B.jb[b] + lane);
+        rec[b] = (uint32_t)(p.i0 + (INDIRECT ? B.jb[b] : (uint32_t)((gw + (B.wl[b] >> 16)) << 6)) + lane);
         if (seen[b])
             rec[b] |= (uint64_t)((px[b] >> 16) & 0xffu) << 32 | (uint64_t)((px[b] >> 8) & 0xffu) << 40 | (uint64_t)(px[b] & 0xffu) << 48 | (1ull << 56);
     }
 #pragma unroll
     for (int b = 0; b < EB; ++b) {
         if ((B.wv[b] >> lane) & 1ull) {
-            const uint64_t o = out0 + B.ws[b] + (uint32_t)__popcll(B.wv[b] & below);
+            const uint64_t o = out0 + (B.wl[b] & 0xffffu) + (uint32_t)__popcll(B.wv[b] & below);
             // (streamed past the caches: 238 MB per step that nothing on the device reads again would evict the masks, images
             // and block grids the next kernels want)
             if (o < p.capacity) __builtin_nontemporal_store(rec[b], &p.records[o]);
@@ -2223,11 +2224,20 @@ __device__ __forceinline__ void emit_group_lanes(const EmitParams &p, const uint
     // colour look-up in a TILE-ordered table: where my word's 64 entries start (4 runs of 16; all lanes at once, once per group)
     const uint32_t tbase = (FROM_LUT && !INDIRECT && p.lut_tq) ? tile_index((uint32_t)((gw + lane) << 6), p.nx, p.ny, p.lut_tq) : 0u;
     uint64_t nz = __ballot(h.mine != 0);
-    EmitBatch<EB> A, B;
+    EmitBatch<EB> A;
+    if (!FROM_LUT) {
+        // projecting every survivor is arithmetic bound: nothing to overlap, and a second batch's state would not fit the registers
+        while (nz != 0) {                                               // wave-uniform
+            emit_prepare<FROM_LUT, EB, INDIRECT>(p, nz, h.mine, h.mybase, wstart, tbase, gw, lane, A);
+            emit_finish<ALLSEEN, EB, INDIRECT>(p, h.out0, gw, lane, A);
+        }
+        return;
+    }
+    EmitBatch<EB> B;
     emit_prepare<FROM_LUT, EB, INDIRECT>(p, nz, h.mine, h.mybase, wstart, tbase, gw, lane, A);
     while (A.any) {                                                     // wave-uniform
         emit_prepare<FROM_LUT, EB, INDIRECT>(p, nz, h.mine, h.mybase, wstart, tbase, gw, lane, B);
-        emit_finish<ALLSEEN, EB>(p, h.out0, lane, A);
+        emit_finish<ALLSEEN, EB, INDIRECT>(p, h.out0, gw, lane, A);
         A = B;
     }
 }
