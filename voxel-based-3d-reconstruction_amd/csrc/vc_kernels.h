@@ -2114,7 +2114,8 @@ struct EmitBatch {
 // takes the next (up to) EB non-zero words of the group off `nz` and starts their table loads (or projects)
 template <bool FROM_LUT, int EB, bool INDIRECT>
 __device__ __forceinline__ void emit_prepare(const EmitParams &p, uint64_t &nz, uint64_t mine, uint32_t mybase, uint32_t wstart,
-                                             uint32_t tbase, uint64_t gw, uint32_t lane, EmitBatch<EB> &B)
+                                             uint32_t tbase, uint64_t gw, uint32_t lane, EmitBatch<EB> &B,
+                                             bool rowwords = false, uint32_t wix = 0, uint32_t wiy = 0, uint32_t wiz = 0)
 {
     B.any = nz != 0;
     uint32_t tb[EB];
@@ -2143,7 +2144,12 @@ __device__ __forceinline__ void emit_prepare(const EmitParams &p, uint64_t &nz, 
                 B.off[b] = p.lut[(!INDIRECT && p.lut_tq) ? tb[b] + ((lane >> 4) << 6) + (lane & 15u) : j];
             } else {
                 uint32_t ix, iy, izl;
-                decompose(j, p.nx, p.ny, ix, iy, izl);
+                if (rowwords) {                                   // (wave-uniform) the word lies in one x-row: its lanes differ in y only
+                    const uint32_t li = B.wl[b] >> 16;
+                    ix = (uint32_t)__builtin_amdgcn_readlane((int)wix, (int)li);
+                    iy = (uint32_t)__builtin_amdgcn_readlane((int)wiy, (int)li) + lane;
+                    izl = (uint32_t)__builtin_amdgcn_readlane((int)wiz, (int)li);
+                } else decompose(j, p.nx, p.ny, ix, iy, izl);
                 double u, v;
                 project_point(p.cam, p.xs[ix], p.ys[iy], p.zs[p.z0 + izl], u, v);
                 B.off[b] = pixel_offset(u, v, p.H, p.W);
@@ -2226,9 +2232,14 @@ __device__ __forceinline__ void emit_group_lanes(const EmitParams &p, const uint
     uint64_t nz = __ballot(h.mine != 0);
     EmitBatch<EB> A;
     if (!FROM_LUT) {
-        // projecting every survivor is arithmetic bound: nothing to overlap, and a second batch's state would not fit the registers
+        // projecting every survivor is arithmetic bound: nothing to overlap, and a second batch's state would not fit the registers.
+        // ny % 64 == 0: a word is 64 consecutive y of one x-row, so (ix, iy of bit 0, iz) are found once per group for all 64
+        // words (lane = word) instead of by two integer divisions per survivor
+        const bool rowwords = (p.ny & 63u) == 0;
+        uint32_t wix = 0, wiy = 0, wiz = 0;
+        if (rowwords) decompose(INDIRECT ? h.mybase : (uint32_t)((gw + lane) << 6), p.nx, p.ny, wix, wiy, wiz);
         while (nz != 0) {                                               // wave-uniform
-            emit_prepare<FROM_LUT, EB, INDIRECT>(p, nz, h.mine, h.mybase, wstart, tbase, gw, lane, A);
+            emit_prepare<FROM_LUT, EB, INDIRECT>(p, nz, h.mine, h.mybase, wstart, tbase, gw, lane, A, rowwords, wix, wiy, wiz);
             emit_finish<ALLSEEN, EB, INDIRECT>(p, h.out0, gw, lane, A);
         }
         return;
