@@ -212,7 +212,8 @@ int vc_fetch_mesh(vc_ctx *ctx, float *verts, uint32_t *faces);
  *   streams         overlap (1)  scan + record expansion of a step on a second stream, beside the next step's carve
  *                                  (single stream while a communicator is attached)
  *   experiments     dbg (0)  bit 0: skip the per-voxel level (undecided words count as alive), bit 1: skip the word level
- *                                  too -- WRONG results on purpose, to time the levels apart (scripts/exp_bricks.py)
+ *                                  too -- WRONG results on purpose, to time the levels apart (scripts/exp_bricks.py); bit 2:
+ *                                  no word-level tests, every word of a listed brick goes to the per-voxel level (right results)
  *   timing          timing_detail (0)  1: vc_carve_begin steps record the events around preparation and carve kernels too
  *                                  (vc_carve always does; see vc_timing_t)
  *   multi-GPU       gather_compact (1)  exchange occupancy words instead of records;
