@@ -172,9 +172,12 @@ def test_every_kernel_family_agrees_with_oracle(eng, seed):
         for opts in ({"lut_hier": 1}, {"bricks": 0}, {"cull": 0}, {"lut_tile": 0}, {"fused_tile": 0}, {"fused_color_table": 1}, {"fused_boxes": 0}, {"fused_boxes": 0, "fused_f32box": 0},
                      {"fused_boxes": 0, "fused_tile": 0}, {"lut_hier": 0}, {"lut_hier": 0, "first_kv": 4}, {"lut_hier": 1, "refine_b": 16, "refine_pair": 0},
                      {"reorder": 0}, {"fused_hier": 0}, {"refine_pair": 0}, {"emit_lanes": 0}, {"emit_busy": 2}, {"emit_busy": 2, "lut_tile": 0, "fused_tile": 0},
+                     {"grid_lds_kb": 64}, {"grid_lds_kb": 148, "voxel_pairs": 2}, {"voxel_pairs": 1},     # 1024-thread workgroups, coarse brick grids
                      {"force_generic": 1}):
             for k, v in opts.items():
                 eng.set_option(k, v)
+            if "grid_lds_kb" in opts:
+                eng.touch_masks(0)                               # (the budget is read when a frame set is prepared)
             for mode in ("lut", "fused"):
                 assert eng.carve(mode=mode, color_cam=2) == want["count"], (opts, mode)
                 idx, rgb, seen = eng.fetch()
@@ -184,9 +187,11 @@ def test_every_kernel_family_agrees_with_oracle(eng, seed):
                 assert np.array_equal(eng.fetch_occupancy(), occ), (opts, mode)
                 assert int(np.bitwise_count(eng.pack_entries()[:, 0]).sum()) == want["count"], (opts, mode)
             for k in opts:
-                eng.set_option(k, {"lut_hier": 1, "bricks": 1, "cull": 1, "lut_tile": 1, "fused_tile": 1, "fused_f32box": 1, "fused_boxes": 1, "fused_color_table": 0, "first_kv": 1, "refine_b": 8, "reorder": 1, "fused_hier": 1, "refine_pair": 1, "emit_lanes": 1, "emit_busy": 1, "force_generic": 0}[k])
+                eng.set_option(k, {"lut_hier": 1, "bricks": 1, "cull": 1, "lut_tile": 1, "fused_tile": 1, "fused_f32box": 1, "fused_boxes": 1, "fused_color_table": 0, "first_kv": 1, "refine_b": 8, "reorder": 1, "fused_hier": 1, "refine_pair": 1, "emit_lanes": 1, "emit_busy": 1, "force_generic": 0, "grid_lds_kb": 0, "voxel_pairs": 0}[k])
+            if "grid_lds_kb" in opts:
+                eng.touch_masks(0)
     finally:
-        for k, v in {"lut_hier": 1, "bricks": 1, "cull": 1, "lut_tile": 1, "fused_tile": 1, "fused_f32box": 1, "fused_boxes": 1, "fused_color_table": 0, "first_kv": 1, "refine_b": 8, "reorder": 1, "fused_hier": 1, "refine_pair": 1, "emit_lanes": 1, "emit_busy": 1, "force_generic": 0}.items():
+        for k, v in {"lut_hier": 1, "bricks": 1, "cull": 1, "lut_tile": 1, "fused_tile": 1, "fused_f32box": 1, "fused_boxes": 1, "fused_color_table": 0, "first_kv": 1, "refine_b": 8, "reorder": 1, "fused_hier": 1, "refine_pair": 1, "emit_lanes": 1, "emit_busy": 1, "force_generic": 0, "grid_lds_kb": 0, "voxel_pairs": 0}.items():
             eng.set_option(k, v)
     with pytest.raises(Exception):
         eng.set_option("no_such_option", 1)

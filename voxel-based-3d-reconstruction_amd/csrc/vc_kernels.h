@@ -127,6 +127,8 @@ struct CarveParams {
     const uint32_t *counts;     // the frame set's per-camera pass counts of a voxel sample, kBoxStride apart (camera visiting order)
     const uint32_t *blockgrid;  // the frame set's header (block size, length, camera order) + per camera (crop[c].off):
                                 // any[ch][cws] then all[ch][cws], one bit per block of 2^shift x 2^shift pixels
+    const uint32_t *coarsegrid; // the same for 4 x 4 times coarser blocks (k_coarsen_grids; large frame sets only, else null): what
+                                // the brick level looks at
     uint64_t *words;
     uint32_t *groupcnt;         // survivors per group of 64 words (kernels that know it write it)
     uint16_t *viewmask;
@@ -1181,7 +1183,7 @@ __device__ __forceinline__ void shard_locate(const ShardView &v, uint32_t t, uin
 __global__ __launch_bounds__(kWideBlock) void k_cull_bricks(const CarveParams p, const BrickLists bl, uint32_t ngroups)
 {
     extern __shared__ uint32_t s_grid[];
-    stage_grids(s_grid, p.blockgrid);
+    stage_grids(s_grid, p.coarsegrid ? p.coarsegrid : p.blockgrid);
     __shared__ uint32_t s_order[kMaxCameras];
     stage_order(p.counts, p.C, s_order);
     if (blockIdx.x == 0 && threadIdx.x < 3 * kShards) bl.counters[((bl.parity ^ 1u) * 3 * kShards + threadIdx.x) * kShardStride] = 0;
@@ -1771,6 +1773,82 @@ __global__ __launch_bounds__(kBlock) void k_prep_grid(const CarveParams p, uint3
 // ---------------------------------------------------------------- compaction
 // Ordered compaction without a sort: survivors per 64-word group -> exclusive scan (two
 // levels) -> one wave per group expands its words into records.
+
+// Large frame sets (blocks of 8 x 8 pixels at 16 cameras x 1080p): a brick's pixel box spans 8 x 8 such blocks and more, the loops
+// of box_test over them cost k_cull_bricks 45 us, and the brick level needs no such resolution.  Once per frame set, behind
+// k_prep_grid: grids of 4 x 4 times coarser blocks in the same format -- "any" = OR, "all" = AND of the 16 blocks (blocks outside
+// a camera's kept rectangle hold no foreground: any = all = 0), aligned to absolute block coordinates, so that box_test reads them
+// unchanged with the shift raised by 2.  Coarser is conservative in both directions ("dead" and "full" stay true statements
+// about the fine blocks).  blockIdx.y = camera; every workgroup works out all descriptors for itself (lane = camera).
+__device__ __forceinline__ uint32_t gather_every_4th_bit(uint32_t x)        // bits 0, 4, .., 28 -> bits 0..7
+{
+    x &= 0x11111111u;
+    x = (x | (x >> 3)) & 0x03030303u;
+    x = (x | (x >> 6)) & 0x000f000fu;
+    return (x | (x >> 12)) & 0xffu;
+}
+__global__ __launch_bounds__(kBlock) void k_coarsen_grids(const uint32_t *__restrict__ fine, uint32_t *__restrict__ coarse, uint32_t C)
+{
+    __shared__ uint32_t s_d[3];                                   // this workgroup's camera: coarse offset, origin, size
+    const uint32_t lane = threadIdx.x & 63u, c = blockIdx.y;
+    if (threadIdx.x < 64u) {
+        uint32_t f1 = 0, f2 = 0;
+        if (lane < C) { f1 = fine[3 * lane + 1]; f2 = fine[3 * lane + 2]; }
+        const uint32_t w_lo = f1 & 0xffffu, v_lo = f1 >> 16, cws = f2 & 0xffffu, ch = f2 >> 16;
+        uint32_t cw_lo = 0, cv_lo = 0, ccws = 0, cch = 0;
+        if (lane < C && ch != 0) {
+            cw_lo = w_lo >> 2; cv_lo = v_lo >> 2;
+            ccws = ((w_lo + cws - 1u) >> 2) - cw_lo + 1u;
+            cch = ((v_lo + ch - 1u) >> 2) - cv_lo + 1u;
+        }
+        const uint32_t size = 2u * ccws * cch;
+        const uint32_t incl = wave_inclusive_scan(size, lane);
+        if (lane == c) { s_d[0] = kGridHeader + incl - size; s_d[1] = cw_lo | (cv_lo << 16); s_d[2] = ccws | (cch << 16); }
+        if (blockIdx.x == 0 && c == 0) {                          // one workgroup writes the header
+            if (lane < kMaxCameras) {
+                coarse[3 * lane] = kGridHeader + incl - size;
+                coarse[3 * lane + 1] = cw_lo | (cv_lo << 16);
+                coarse[3 * lane + 2] = ccws | (cch << 16);
+            }
+            if (lane == 63u) { coarse[kHdrShift] = fine[kHdrShift] + 2u; coarse[kHdrWords] = kGridHeader + incl; }
+        }
+    }
+    __syncthreads();
+    const uint32_t f0 = fine[3 * c], f1 = fine[3 * c + 1], f2 = fine[3 * c + 2];
+    const uint32_t w_lo = f1 & 0xffffu, v_lo = f1 >> 16, cws = f2 & 0xffffu, ch = f2 >> 16;
+    const uint32_t cw_lo = s_d[1] & 0xffffu, cv_lo = s_d[1] >> 16, ccws = s_d[2] & 0xffffu, cch = s_d[2] >> 16;
+    const uint32_t *__restrict__ g_any = fine + f0;
+    const uint32_t *__restrict__ g_all = g_any + ch * cws;
+    uint32_t *o_any = coarse + s_d[0];
+    uint32_t *o_all = o_any + cch * ccws;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < ccws * cch; i += gridDim.x * kBlock) {
+        const uint32_t R = i / ccws, Cw = i - R * ccws;
+        const uint32_t fr0 = 4u * (cv_lo + R), fw0 = 4u * (cw_lo + Cw);        // first fine row / word under this coarse word
+        uint32_t cany = 0, call = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t fw = fw0 + j;
+            const bool wok = fw >= w_lo && fw < w_lo + cws;
+            uint32_t a[4], l[4];
+#pragma unroll
+            for (uint32_t r = 0; r < 4; ++r) {                    // (clamped addresses: the eight loads go out together)
+                const uint32_t fr = fr0 + r;
+                const bool ok = wok && fr >= v_lo && fr < v_lo + ch;
+                const uint32_t at = ok ? (fr - v_lo) * cws + (fw - w_lo) : 0u;
+                a[r] = g_any[at]; l[r] = g_all[at];
+                if (!ok) { a[r] = 0u; l[r] = 0u; }
+            }
+            uint32_t anyrow = a[0] | a[1] | a[2] | a[3], allrow = l[0] & l[1] & l[2] & l[3];
+            anyrow |= anyrow >> 1; anyrow |= anyrow >> 2;         // bit 4 q = OR of bits 4 q .. 4 q + 3
+            allrow &= allrow >> 1; allrow &= allrow >> 2;         // bit 4 q = AND of bits 4 q .. 4 q + 3
+            cany |= gather_every_4th_bit(anyrow) << (8u * j);
+            call |= gather_every_4th_bit(allrow) << (8u * j);
+        }
+        o_any[i] = cany;
+        o_all[i] = call;
+    }
+}
+
 
 // For the kernels that do not write groupcnt themselves (fused, generic): one wave per group.
 __global__ __launch_bounds__(kBlock) void k_count_groups(const uint64_t *__restrict__ words, uint64_t nwords,

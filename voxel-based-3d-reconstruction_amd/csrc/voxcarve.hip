@@ -102,6 +102,8 @@ struct Slot {
     bool bits_valid = false;    // bits, BGRX images and the grid plan match the staged bytes
     bool grids_valid = false;   // block grids and camera order too (they also depend on grid, slab and cameras)
     DevBuf<uint32_t> grid;      // header + cropped block grids of all cameras (hierarchical kernels stage it in LDS)
+    DevBuf<uint32_t> coarse;    // the same with 4 x 4 times coarser blocks, for the brick level (frame sets with large grids only)
+    bool has_coarse = false;
     DevBuf<uint32_t> boxes;     // the cameras' foreground pixel boxes, two sets (see kBoxStride)
     uint32_t budget_words = 0;  // LDS budget the plan was made for (fixes the dynamic LDS size of the carve launch)
     uint32_t parity = 0;        // which of the header's two foreground-box sets the current frame filled
@@ -369,6 +371,7 @@ constexpr uint32_t kMaxScanBlocks = 1024;  // 2^32 voxels / 4096 per group / 102
 constexpr int kSub = 4;                    // 64-voxel sub-chunks per wavefront chunk (fused kernel)
 constexpr size_t kLdsBytes = 160 * 1024;   // LDS per CU on gfx950
 constexpr size_t kMaxFirstLds = 64 * 1024; // static limit of one workgroup's dynamic LDS without opt-in
+constexpr size_t kWideGridBytes = 20 * 1024; // grids above this: 1024-thread workgroups share a copy, the brick level reads coarser blocks
 constexpr size_t kMaxWideLds = 152 * 1024; // what the brick pipeline's grid-staging kernels may take (one 1024-thread workgroup per CU)
 constexpr uint32_t kEstimateSamples = 1u << 16;
 
@@ -447,7 +450,7 @@ int launch_bricks(vc_ctx *ctx, CarveParams &p, size_t lds, uint32_t ngroups)
     const uint32_t k_bricks = known[0], k_cols = known[1], k_words = known[2];
     // large grids (many cameras x large images): 16 waves share one LDS copy, so that the compute units stay full of waves
     // with two or three workgroups each; no more workgroups than fit the chip at once (they stride over the lists)
-    const bool wide = lds > 20480;
+    const bool wide = lds > kWideGridBytes;
     const uint32_t wpg = wide ? kWideBlock / 64 : kBlock / 64;                // waves per workgroup
     const dim3 block(kBlock), gblock(wpg * 64);
     const uint32_t fit = 256u * (uint32_t)(kLdsBytes / (lds ? lds : 1) < 1 ? 1 : kLdsBytes / (lds ? lds : 1));
@@ -494,7 +497,8 @@ int slot_at(vc_ctx *ctx, uint32_t slot, Slot **out)
 
 void release_slot(Slot &s)
 {
-    release(s.bytes); release(s.bits); release(s.frames); release(s.grid); release(s.boxes);
+    release(s.bytes); release(s.bits); release(s.frames); release(s.grid); release(s.coarse); release(s.boxes);
+    s.has_coarse = false;
     for (int c = 0; c < VC_MAX_CAMERAS; ++c) {
         release(s.fbytes[c]);
         if (s.h_fbytes[c]) { (void)hipHostFree(s.h_fbytes[c]); s.h_fbytes[c] = nullptr; }
@@ -617,6 +621,14 @@ int ensure_prepared(vc_ctx *ctx, Slot &s, bool want_grids, const CarveParams *cp
         hipLaunchKernelGGL(k_prep_grid, dim3(grid_wgs + est_wgs), dim3(kBlock), 0, st, p,
                            s.grid.ptr, s.boxes.ptr, s.parity, (uint32_t)ctx->grid_min_shift, s.budget_words, ns, grid_wgs);
         VC_HIP(ctx, hipGetLastError());
+        // large grids (the brick pipeline's 1024-thread workgroups): the brick level gets 4 x 4 times coarser blocks
+        s.has_coarse = false;
+        if ((size_t)s.budget_words * sizeof(uint32_t) > kWideGridBytes) {
+            VC_TRY(ensure(ctx, s.coarse, (size_t)s.budget_words + 8));       // (never larger than the fine grids)
+            hipLaunchKernelGGL(k_coarsen_grids, dim3(8, C), dim3(kBlock), 0, st, (const uint32_t *)s.grid.ptr, s.coarse.ptr, C);
+            VC_HIP(ctx, hipGetLastError());
+            s.has_coarse = true;
+        }
         s.grids_valid = true;
     }
     VC_HIP(ctx, hipEventRecord(s.e_prep, st));
@@ -1357,6 +1369,7 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     if (s.prep_pending) { VC_HIP(ctx, hipStreamWaitEvent(ctx->stream, s.e_prep, 0)); s.prep_pending = false; }
     p.maskbits = s.bits.ptr;
     p.blockgrid = s.grid.ptr;
+    p.coarsegrid = s.has_coarse ? s.coarse.ptr : nullptr;
     p.counts = s.boxes.ptr + kCountBase;
     // which table the step reads: the tile-ordered one (hierarchical kernels on tile words), else the y-major one
     const bool lut_tiled = mode == VC_MODE_LUT && fast && ctx->lut_hier && ctx->lut_tile && ctx->tile_valid;
