@@ -7,7 +7,7 @@
 // grid shape allows, a tile of 4 x-rows x 16 y (compact footprint, tighter pixel box); results always
 // leave the kernels as y-major words.
 //
-//   per frame set   k_morph2x2 (optional), k_prep_pack, k_prep_grid: two launches, nothing returns to the host
+//   per frame set   k_morph2x2 (optional), k_prep_pack, k_prep_grid (+ k_coarsen_grids for large grids): nothing returns to the host
 //   per geometry    k_build_lut<TILE> (table and/or word boxes), k_brick_boxes_bm
 //   carve           k_cull_bricks, k_brick_words, k_voxel_words<LUT,PAIR>, k_assemble   the brick pipeline (default for
 //                                                    ny in {256, 512, 1024, 2048, 4096}; see its section below)
