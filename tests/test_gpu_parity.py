@@ -1071,8 +1071,10 @@ def test_property_random_shapes_cameras_masks(eng):
     @settings(max_examples=60, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
     @given(seed=st.integers(0, 10 ** 6), nx=st.integers(1, 6), ny=st.sampled_from([1, 7, 16, 63, 64, 65, 128, 192, 200, 256, 256, 512, 2048]),
            nz=st.integers(1, 9), C=st.integers(1, 5), H=st.integers(8, 70), W=st.integers(8, 90),
-           kind=st.sampled_from(["noise", "blob", "empty", "full", "sparse"]), below=st.booleans(), quad=st.booleans())
-    def check(seed, nx, ny, nz, C, H, W, kind, below, quad):
+           kind=st.sampled_from(["noise", "blob", "empty", "full", "sparse"]), below=st.booleans(), quad=st.booleans(),
+           lds_kb=st.sampled_from([0, 0, 64, 148]))
+    def check(seed, nx, ny, nz, C, H, W, kind, below, quad, lds_kb):
+        # lds_kb > 20: the brick pipeline's 1024-thread workgroups and the coarse brick-level grids (k_coarsen_grids)
         # quad: nx % 4 == 0, so ny % 64 == 0 shapes take the tile kernels; ny = 256 / 512 with nx % 16 / 8 == 0 and ny = 2048 the brick pipeline
         nxx = nx * (16 if ny == 256 else 8 if ny == 512 else 4) if quad else nx
         cams3, masks3, frames3 = fx.random_scene(seed, C=C, H=H, W=W, fg=0.5)
@@ -1092,16 +1094,20 @@ def test_property_random_shapes_cameras_masks(eng):
         cc = int(rng.integers(0, C))
         want = carve_c.carve(nxx, ny, nz, fx.oracle_cams(cams3), masks3, frames3, min_views=mv, color_cam=cc, want_viewmask=True)
         seen_want = ((want["viewmask"][want["idx"]] >> cc) & 1).astype(bool)
-        eng.set_grid(nxx, ny, nz)
-        eng.set_cameras(cams3, H, W)
-        eng.upload_masks(masks3)
-        eng.upload_frame(cc, frames3[cc])
-        eng.build_lut()
-        for mode in ("lut", "fused"):
-            assert eng.carve(mode=mode, min_views=mv, color_cam=cc) == want["count"], (mode,)
-            idx, rgb, seen = eng.fetch()
-            assert np.array_equal(idx, want["idx"]) and np.array_equal(seen, seen_want), (mode,)
-            assert np.array_equal(rgb[:, ::-1], want["bgr"]), (mode,)
+        eng.set_option("grid_lds_kb", lds_kb)
+        try:
+            eng.set_grid(nxx, ny, nz)
+            eng.set_cameras(cams3, H, W)
+            eng.upload_masks(masks3)
+            eng.upload_frame(cc, frames3[cc])
+            eng.build_lut()
+            for mode in ("lut", "fused"):
+                assert eng.carve(mode=mode, min_views=mv, color_cam=cc) == want["count"], (mode,)
+                idx, rgb, seen = eng.fetch()
+                assert np.array_equal(idx, want["idx"]) and np.array_equal(seen, seen_want), (mode,)
+                assert np.array_equal(rgb[:, ::-1], want["bgr"]), (mode,)
+        finally:
+            eng.set_option("grid_lds_kb", 0)
 
     check()
 
