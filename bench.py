@@ -496,6 +496,13 @@ def main():
                     "records only the two events the streams exchange anyway"})
     if head.get("ms_per_step_resident_prep") is not None:
         phases["ms_per_step_with_frame_sets_prepared_once"] = round(head["ms_per_step_resident_prep"], 4)
+    # the same kernel without the other stream's kernels beside it (short one-stream side run): how fast it is by itself
+    if roof is not None and "one_stream" in head and roof.get("algorithmic_bytes_per_launch") and "k_emit_busy" in roof["kernel"]:
+        o = head["one_stream"]["tm"]
+        if o["emit_launches"]:
+            alone_ms = o["emit_ms_sum"] / o["emit_launches"]
+            roof["avg_launch_ms_alone"] = round(alone_ms, 4)
+            roof["frac_alone"] = round(roof["algorithmic_bytes_per_launch"] / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     out = {
         "metric": "Mvoxel-views/s (grid N^3 x 4 cams)", "value": round(value, 1), "unit": "Mvoxel-views/s",
         "n_gpus": grp.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
