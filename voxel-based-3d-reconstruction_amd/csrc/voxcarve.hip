@@ -168,6 +168,7 @@ struct StepBuf {
     uint64_t n = 0, survivors = 0;
 };
 
+constexpr uint32_t kGatherRing = 32;        // steps before a gather's events are recorded again (more than the resident frame sets a stream cycles through)
 struct vc_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -179,6 +180,11 @@ struct vc_ctx {
     StepBuf sb[2];
     int head = 0, npending = 0, cur = -1;    // next set to issue into, steps in flight, set holding the fetched result
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // the compact all-gather's events {start, expansion done, payload arrived}, a RING of them: a frame set's next preparation
+    // waits for the expansion that read it (Slot::e_emit), many steps later -- one event re-recorded every step would make it
+    // wait for the newest expansion instead and put carve, exchange, expansion and preparation in one line
+    hipEvent_t gx[kGatherRing][3] = {};
+    uint32_t gx_next = 0, gx_cur = 0;
     std::string err;
 
     // grid
@@ -781,9 +787,10 @@ int finish_gather(vc_ctx *ctx)
 {
     if (!ctx->gather_pending) return VC_OK;
     ctx->gather_pending = false;
-    VC_HIP(ctx, hipEventSynchronize(ctx->ev[1]));
-    VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.gather_ms, ctx->ev[0], ctx->ev[1]));
-    VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.exchange_ms, ctx->ev[0], ctx->ev[2]));
+    hipEvent_t *E = ctx->gx[ctx->gx_cur];
+    VC_HIP(ctx, hipEventSynchronize(E[1]));
+    VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.gather_ms, E[0], E[1]));
+    VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.exchange_ms, E[0], E[2]));
     ctx->tm.gather_ms_sum += ctx->tm.gather_ms;
     ctx->tm.gathers += 1;
     if (ctx->gather_expect && *(ctx->h_xtotal + 1) != ctx->gather_expect)
@@ -896,6 +903,8 @@ int vc_create(int device, vc_ctx **out)
         if (e1 == hipSuccess) e1 = hipHostMalloc(reinterpret_cast<void **>(&b.h_total), sizeof(uint64_t), hipHostMallocDefault);
     }
     for (int i = 0; i < 4 && e1 == hipSuccess; ++i) e1 = hipEventCreate(&ctx->ev[i]);
+    for (uint32_t r = 0; r < kGatherRing && e1 == hipSuccess; ++r)
+        for (int i = 0; i < 3 && e1 == hipSuccess; ++i) e1 = hipEventCreate(&ctx->gx[r][i]);
     if (e1 == hipSuccess) e1 = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_total), sizeof(uint64_t), hipHostMallocDefault);
     const char *fg = getenv("VOXCARVE_FORCE_GENERIC");
     ctx->force_generic = fg && fg[0] == '1';
@@ -923,6 +932,8 @@ int vc_destroy(vc_ctx *ctx)
         if (s.e_p0) (void)hipEventDestroy(s.e_p0);
     }
     for (int k = 0; k < 2; ++k) if (ctx->ev_h[k]) (void)hipEventDestroy(ctx->ev_h[k]);
+    for (uint32_t r = 0; r < kGatherRing; ++r)
+        for (int i = 0; i < 3; ++i) if (ctx->gx[r][i]) (void)hipEventDestroy(ctx->gx[r][i]);
     release(ctx->d_axes); release(ctx->d_morph); release(ctx->d_lut); release(ctx->d_bbox); release(ctx->d_lut_tile); release(ctx->d_tbox); release(ctx->d_kbox); release(ctx->d_live); release(ctx->d_wbox); release(ctx->d_bm); release(ctx->d_blist); release(ctx->d_wlist);
     release(ctx->d_mcbits); release(ctx->d_mcx); release(ctx->d_mcwbase); release(ctx->d_mcgv); release(ctx->d_mcgt); release(ctx->d_mcgvoff);
     release(ctx->d_mcgtoff); release(ctx->d_mcfaces); release(ctx->d_mcbv); release(ctx->d_mcbvoff); release(ctx->d_mcbt); release(ctx->d_mcbtoff);
@@ -1996,8 +2007,11 @@ static int allgather_compact(vc_ctx *ctx, uint64_t *counts_out, uint64_t *total_
 {
     const int G = ctx->n_ranks;
     StepBuf &cur = ctx->sb[ctx->cur];
-    VC_TRY(finish_gather(ctx));
-    VC_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    VC_TRY(finish_gather(ctx));                                  // (the previous expansion still reads d_ent_all)
+    hipEvent_t *E = ctx->gx[ctx->gx_next];                       // this gather's own events: see vc_ctx::gx
+    ctx->gx_cur = ctx->gx_next;
+    ctx->gx_next = (ctx->gx_next + 1) % kGatherRing;
+    VC_HIP(ctx, hipEventRecord(E[0], ctx->stream));
     if (!cur.counts_exchanged) {                 // vc_carve_begin did not do it (records were kept)
         VC_TRY(enqueue_pack(ctx, cur));
         VC_TRY(enqueue_counts_exchange(ctx, cur));
@@ -2022,15 +2036,15 @@ static int allgather_compact(vc_ctx *ctx, uint64_t *counts_out, uint64_t *total_
         disp += cnt;
     }
     VC_NCCL(ctx, g_rccl.GroupEnd());
-    VC_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    VC_HIP(ctx, hipEventRecord(E[2], ctx->stream));
     // the expansion runs beside the next step's carve (second stream) when the call does not wait for it anyway
     hipStream_t xs = (ctx->overlap && !ctx->gather_sync) ? ctx->stream2 : ctx->stream;
-    if (xs != ctx->stream) VC_HIP(ctx, hipStreamWaitEvent(xs, ctx->ev[2], 0));
+    if (xs != ctx->stream) VC_HIP(ctx, hipStreamWaitEvent(xs, E[2], 0));
     if (S) VC_TRY(enqueue_expand(ctx, xs, ctx->d_ent_all.ptr, M, S));
-    VC_HIP(ctx, hipEventRecord(ctx->ev[1], xs));
+    VC_HIP(ctx, hipEventRecord(E[1], xs));
     if (S && cur.color_cam >= 0 && xs != ctx->stream) {          // the expansion reads the slot's bits / images beside the carve stream
         Slot &sl = ctx->slots[cur.slot];
-        sl.e_emit = ctx->ev[1];
+        sl.e_emit = E[1];
         sl.emit_pending = true;
     }
     ctx->gather_pending = true;
