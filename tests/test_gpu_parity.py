@@ -689,7 +689,31 @@ def test_rccl_allgather_single_rank(eng, cams, masks, frames):
         assert eng.carve_end() == 0 and eng.allgather()[1] == 0
         assert eng.carve_end() == 0 and eng.allgather()[1] == 0
     eng.set_slab(0, 64)
+    # a brick-pipeline shape and a slab that does not start at layer 0: the rank packs from the non-zero-word counts k_assemble
+    # leaves and over the list of groups with survivors (k_pack_busy; emit_busy 2 builds the list on a grid this small)
     eng.comm_destroy()
+    setup_real(eng, cams, masks, frames, (32, 256, 72))
+    eng.build_lut()
+    eng.comm_init(1, 0, voxcarve.CarveEngine.comm_unique_id())
+    try:
+        for busy in (2, 1):
+            eng.set_option("emit_busy", busy)
+            for z0, z1 in ((0, 72), (16, 72), (23, 57)):
+                eng.set_slab(z0, z1)
+                eng.build_lut()                                   # (the table belongs to the slab)
+                for mode in ("lut", "fused"):
+                    n_i = eng.carve(mode=mode)
+                    want_rec = eng.fetch_records()
+                    assert n_i > 0
+                    eng.carve_begin(mode=mode, records=False)
+                    assert eng.carve_end() == n_i
+                    counts, total = eng.allgather()
+                    assert counts.tolist() == [n_i] and total == n_i
+                    assert np.array_equal(eng.fetch_gathered(), want_rec), (busy, z0, z1, mode)
+    finally:
+        eng.set_option("emit_busy", 1)
+        eng.set_slab(0, 72)
+        eng.comm_destroy()
 
 
 def test_drop_in_module_surface(built, cams, masks, frames):
@@ -1027,8 +1051,10 @@ def test_bench_contract_single_gpu(built):
     assert d["config"]["survivors_frame_set_0"] == 461113 and d["config"]["ranks_agree_on_records"] is True
     # every timed step prepared its frame set on the device, inside the timed region; the PCIe-inclusive figure is there
     ph = d["phases_ms"]
-    assert ph["steps_that_prepared"] == 7 and 0 < ph["frame_set_prep_on_device"] < d["ms_per_step"]
-    assert 0 < ph["carve_kernels"] < d["ms_per_step"] and ph["record_expansion"] > 0
+    # (the prep / carve figures come from a side run with extra events and from kernels that run beside other streams' kernels:
+    # at 256^3 they are of the order of the step itself, so only their order of magnitude is checked)
+    assert ph["steps_that_prepared"] == 7 and 0 < ph["frame_set_prep_on_device"] < 3 * d["ms_per_step"]
+    assert 0 < ph["carve_kernels"] < 3 * d["ms_per_step"] and ph["record_expansion"] > 0
     assert d["pcie_inclusive"]["value"] > 0 and d["pcie_inclusive"]["value"] < d["value"]
 
 

@@ -131,6 +131,7 @@ struct CarveParams {
                                 // the brick level looks at
     uint64_t *words;
     uint32_t *groupcnt;         // survivors per group of 64 words (kernels that know it write it)
+    uint32_t *groupnz;          // non-zero words per group, or null (brick pipeline with tq <= 64: what the compact exchange packs by)
     uint16_t *viewmask;
     uint64_t n;                 // voxels in the slab (< 2^32)
     uint64_t n_pad;             // LUT camera stride: n rounded up to kLutPad, tail entries = -1
@@ -1194,7 +1195,10 @@ __global__ __launch_bounds__(kWideBlock) void k_cull_bricks(const CarveParams p,
     const uint32_t nwaves = gridDim.x * (blockDim.x / 64);
     const uint32_t nw = p.nbrick_pad >> 6;
     const uint32_t nbricks = p.nbx * p.tq * p.nbz;
-    for (uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x); i < ngroups; i += gridDim.x * blockDim.x) p.groupcnt[i] = 0;
+    for (uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x); i < ngroups; i += gridDim.x * blockDim.x) {
+        p.groupcnt[i] = 0;
+        if (p.groupnz) p.groupnz[i] = 0;
+    }
     // a wave takes 64 bricks at a time; a brick column has tq of them: 64 / tq whole columns per wave (ny <= 1024), or one column
     // in tq / 64 rounds (ny = 2048, 4096), so that a column is listed once, by one wave
     const uint32_t ipw = p.tq > 64u ? p.tq / 64u : 1u;
@@ -1503,7 +1507,11 @@ __global__ __launch_bounds__(kBlock) void k_assemble(const CarveParams p, const 
                 const uint32_t k4 = 4u * (lane & 15u), dqk = k4 >> tqs, tyk = k4 & (p.tq - 1u);
                 if (qx0 + dqk < qpl)
                     p.words[(((uint64_t)izl * p.nx + (qx0 + dqk) * 4 + (lane >> 4)) * p.ny + (uint64_t)tyk * 16) >> 6] = out[xg];
-                if (lane == 0) p.groupcnt[gw >> 6] = cnt[xg];
+                const uint64_t nzw = __ballot(out[xg] != 0ull);   // (lane (r, k) holds y-major word 16 r + k of the group: all 64 of them)
+                if (lane == 0) {
+                    p.groupcnt[gw >> 6] = cnt[xg];
+                    if (p.groupnz) p.groupnz[gw >> 6] = (uint32_t)__popcll(nzw);
+                }
             }
         }
     }
@@ -1914,6 +1922,31 @@ __global__ __launch_bounds__(kBlock) void k_pack_entries(const uint64_t *__restr
         const uint64_t o = blockoff[g / kScanBlock] + groupoff[g] + (uint32_t)__popcll(nz & ((1ull << lane) - 1ull));
         entries[2 * o] = bits;
         entries[2 * o + 1] = i0 + (w << 6);
+    }
+}
+
+// The same over the list of groups with survivors (k_finish_scan), offsets from the scan of the counts k_assemble left.
+__global__ __launch_bounds__(kBlock) void k_pack_busy(const uint64_t *__restrict__ words, uint64_t nwords,
+                                                      const uint32_t *__restrict__ busylist, const uint32_t *__restrict__ busycount,
+                                                      const uint32_t *__restrict__ groupoff, const uint64_t *__restrict__ blockoff,
+                                                      uint32_t nscan, uint64_t i0, const uint64_t *__restrict__ survivors,
+                                                      uint64_t *__restrict__ entries, uint64_t *__restrict__ mine)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t w0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
+    const uint32_t nwaves = gridDim.x * (kBlock / 64);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { mine[0] = blockoff[nscan]; mine[1] = *survivors; }
+    const uint32_t nbusy = busycount[0];
+    for (uint32_t t = w0; t < nbusy; t += nwaves) {
+        const uint32_t g = busylist[t];
+        const uint64_t w = (uint64_t)g * kGroupWords + lane;
+        const uint64_t bits = (w < nwords) ? words[w] : 0ull;
+        const uint64_t nz = __ballot(bits != 0ull);
+        if (bits != 0ull) {
+            const uint64_t o = blockoff[g / kScanBlock] + groupoff[g] + (uint32_t)__popcll(nz & ((1ull << lane) - 1ull));
+            entries[2 * o] = bits;
+            entries[2 * o + 1] = i0 + (w << 6);
+        }
     }
 }
 

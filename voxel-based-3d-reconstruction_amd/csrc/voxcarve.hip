@@ -145,6 +145,8 @@ void linspace(double lo, double hi, uint32_t n, std::vector<double> &out)
 struct StepBuf {
     DevBuf<uint64_t> words;
     DevBuf<uint32_t> groupcnt, groupoff;
+    DevBuf<uint32_t> groupnz;                // non-zero words per group (brick pipeline, compact exchange: k_assemble counts them in passing)
+    bool nz_valid = false;
     DevBuf<uint64_t> blocksum, blockoff;     // blockoff[nscan] = total
     DevBuf<uint64_t> records;
     uint64_t *h_total = nullptr;             // pinned
@@ -740,6 +742,16 @@ int enqueue_pack(vc_ctx *ctx, StepBuf &cur)
     VC_TRY(ensure_exchange_scratch(ctx, ngroups));
     VC_TRY(ensure(ctx, cur.ent, (size_t)(2 * nwords)));          // worst case: every word non-zero (n / 4 bytes)
     const dim3 grid((ngroups + 3) / 4), block(kBlock);
+    if (cur.nz_valid && cur.busy) {
+        // the carve left the counts of non-zero words and the list of groups with survivors: no counting pass, and the packing
+        // strides over the list (5 of 6 groups are empty; a launch over all of them is dispatch bound)
+        VC_TRY(scan_counts(ctx, ctx->stream, cur.groupnz.ptr, ngroups, ctx->d_xoff.ptr, ctx->d_xbsum.ptr, ctx->d_xboff.ptr, ctx->h_xtotal));
+        hipLaunchKernelGGL(k_pack_busy, dim3(1024), block, 0, ctx->stream, (const uint64_t *)cur.words.ptr, nwords, (const uint32_t *)cur.busylist.ptr,
+                           (const uint32_t *)cur.busyblock.ptr, (const uint32_t *)ctx->d_xoff.ptr, (const uint64_t *)ctx->d_xboff.ptr, nscan, ctx->i0(),
+                           (const uint64_t *)(cur.blockoff.ptr + nscan), cur.ent.ptr, cur.mine.ptr);
+        VC_HIP(ctx, hipGetLastError());
+        return VC_OK;
+    }
     hipLaunchKernelGGL(k_count_nz, grid, block, 0, ctx->stream, cur.words.ptr, nwords, ngroups, cur.groupcnt.ptr,
                        ctx->d_xcnt.ptr);
     VC_HIP(ctx, hipGetLastError());
@@ -1377,6 +1389,12 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     if (fused_tiles) VC_TRY(ensure_boxes(ctx, true));
     const bool bricks = fast && brick_shape(ctx, p) && (fused_tiles || (mode == VC_MODE_LUT && ctx->lut_hier && ctx->lut_tile && ctx->tile_valid));
     VC_TRY(ensure_prepared(ctx, s, fast, &p, sb.prep_timed, bricks));
+    sb.nz_valid = false;
+    if (auto_exchange && bricks && p.tile_whole) {               // k_assemble counts the groups' non-zero words for the packing
+        VC_TRY(ensure(ctx, sb.groupnz, ngroups));
+        p.groupnz = sb.groupnz.ptr;
+        sb.nz_valid = true;
+    }
     if (s.prep_pending) { VC_HIP(ctx, hipStreamWaitEvent(ctx->stream, s.e_prep, 0)); s.prep_pending = false; }
     p.maskbits = s.bits.ptr;
     p.blockgrid = s.grid.ptr;
@@ -1515,7 +1533,9 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
         VC_HIP(ctx, hipGetLastError());
     }
     // the expansion of a large grid iterates over the list of groups that have survivors, made by the same scan
-    sb.busy = ctx->emit_lanes && !sb.no_records && (ctx->emit_busy == 2 || (ctx->emit_busy == 1 && ngroups >= kBusyListMinGroups));
+    // (a rank of a communicator has no expansion of its own, but its packing strides over the same list)
+    sb.busy = ctx->emit_lanes && (!sb.no_records || (auto_exchange && sb.nz_valid)) &&
+              (ctx->emit_busy == 2 || (ctx->emit_busy == 1 && ngroups >= kBusyListMinGroups));
     if (sb.busy) {
         VC_TRY(ensure(ctx, sb.busyoff, ngroups));
         VC_TRY(ensure(ctx, sb.busylist, ngroups));
