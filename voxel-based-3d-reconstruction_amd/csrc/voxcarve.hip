@@ -186,7 +186,7 @@ struct vc_ctx {
     // waits for the expansion that read it (Slot::e_emit), many steps later -- one event re-recorded every step would make it
     // wait for the newest expansion instead and put carve, exchange, expansion and preparation in one line
     hipEvent_t gx[kGatherRing][3] = {};
-    uint32_t gx_next = 0, gx_cur = 0;
+    uint32_t gx_next = 0;
     std::string err;
 
     // grid
@@ -277,9 +277,14 @@ struct vc_ctx {
     // compact exchange: non-zero words of the slab as {bits, global index of bit 0} pairs
     int gather_compact = 1;          // vc_allgather exchanges the pairs and expands them on every rank
     int gather_sync = 1;             // 0: vc_allgather returns once its work is queued (count known from the ranks' counts)
-    bool gather_pending = false;     // a queued all-gather whose completion has not been observed yet
-    uint64_t gather_expect = 0;
-    DevBuf<uint64_t> d_ent_all;              // all ranks' pairs in rank order
+    // Two compact gathers may be in flight (gather_sync 0): gather k uses half k & 1 of what follows -- its payload buffer
+    // (all ranks' pairs in rank order: the next payload arrives while the expansion of this one still reads it), its events, its
+    // expected total.  The records go to the one d_gathered: expansions are in order on their stream and a read-back ends them.
+    bool gpend[2] = {false, false};  // a queued all-gather whose completion has not been observed yet
+    uint32_t gx_idx[2] = {0, 0};
+    uint64_t gexpect[2] = {0, 0};
+    uint32_t gseq = 0;               // compact gathers issued
+    DevBuf<uint64_t> d_ent_all[2];
     DevBuf<uint32_t> d_xcnt, d_xoff;         // scan scratch of the pack pass ...
     DevBuf<uint64_t> d_xbsum, d_xboff;
     DevBuf<uint32_t> d_ycnt, d_yoff;         // ... and of the expansion, which may run on the second stream beside a pack
@@ -698,7 +703,7 @@ int ensure_exchange_scratch(vc_ctx *ctx, uint32_t ngroups)
     VC_TRY(ensure(ctx, ctx->d_xbsum, kMaxScanBlocks));
     VC_TRY(ensure(ctx, ctx->d_xboff, kMaxScanBlocks + 1));
     if (!ctx->h_xtotal)
-        VC_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_xtotal), 2 * sizeof(uint64_t), hipHostMallocDefault));
+        VC_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_xtotal), 4 * sizeof(uint64_t), hipHostMallocDefault));   // [2], [3]: the two gathers in flight
     return VC_OK;
 }
 
@@ -795,20 +800,26 @@ int ensure_color_table(vc_ctx *ctx, int cam)
 
 // Observes the completion of a queued all-gather: its timing, and that the expansion produced
 // the survivor count the ranks announced.
-int finish_gather(vc_ctx *ctx)
+static int finish_one(vc_ctx *ctx, uint32_t half)
 {
-    if (!ctx->gather_pending) return VC_OK;
-    ctx->gather_pending = false;
-    hipEvent_t *E = ctx->gx[ctx->gx_cur];
+    if (!ctx->gpend[half]) return VC_OK;
+    ctx->gpend[half] = false;
+    hipEvent_t *E = ctx->gx[ctx->gx_idx[half]];
     VC_HIP(ctx, hipEventSynchronize(E[1]));
     VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.gather_ms, E[0], E[1]));
     VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.exchange_ms, E[0], E[2]));
     ctx->tm.gather_ms_sum += ctx->tm.gather_ms;
     ctx->tm.gathers += 1;
-    if (ctx->gather_expect && *(ctx->h_xtotal + 1) != ctx->gather_expect)
+    if (ctx->gexpect[half] && ctx->h_xtotal[2 + half] != ctx->gexpect[half])
         return fail(ctx, VC_ERR_RCCL, "gathered words expand to %llu survivors, the ranks reported %llu",
-                    (unsigned long long)*(ctx->h_xtotal + 1), (unsigned long long)ctx->gather_expect);
+                    (unsigned long long)ctx->h_xtotal[2 + half], (unsigned long long)ctx->gexpect[half]);
     return VC_OK;
+}
+// every queued compact gather, oldest first
+int finish_gather(vc_ctx *ctx)
+{
+    VC_TRY(finish_one(ctx, ctx->gseq & 1u));
+    return finish_one(ctx, (ctx->gseq + 1u) & 1u);
 }
 
 // Expands M gathered entries (device, ascending) into the ordered survivor records of the whole grid
@@ -816,10 +827,11 @@ int finish_gather(vc_ctx *ctx)
 // S_hint = expected survivor count (0 = unknown: sized after a host synchronisation).
 // st: the stream the expansion runs on (the second stream lets it run beside the next step's carve; its scan
 // scratch is its own because the next step's packing may be under way on the first).
-int enqueue_expand(vc_ctx *ctx, hipStream_t st, const uint64_t *d_entries, uint64_t M, uint64_t S_hint)
+int enqueue_expand(vc_ctx *ctx, hipStream_t st, const uint64_t *d_entries, uint64_t M, uint64_t S_hint, uint64_t *h_total = nullptr)
 {
     StepBuf &cur = ctx->sb[ctx->cur];
-    *(ctx->h_xtotal + 1) = 0;
+    if (!h_total) h_total = ctx->h_xtotal + 1;                   // (page-locked word the scan leaves the survivor total in)
+    *h_total = 0;
     if (M == 0) return VC_OK;
     const uint32_t ngroups = (uint32_t)((M + kGroupWords - 1) / kGroupWords);
     VC_TRY(ensure_exchange_scratch(ctx, 1));
@@ -835,10 +847,10 @@ int enqueue_expand(vc_ctx *ctx, hipStream_t st, const uint64_t *d_entries, uint6
     const dim3 grid((ngroups + 3) / 4), block(kBlock);
     hipLaunchKernelGGL(k_count_entries, grid, block, 0, st, d_entries, M, ngroups, ctx->d_ycnt.ptr);
     VC_HIP(ctx, hipGetLastError());
-    VC_TRY(scan_counts(ctx, st, ctx->d_ycnt.ptr, ngroups, ctx->d_yoff.ptr, ctx->d_ybsum.ptr, ctx->d_yboff.ptr, ctx->h_xtotal + 1));
+    VC_TRY(scan_counts(ctx, st, ctx->d_ycnt.ptr, ngroups, ctx->d_yoff.ptr, ctx->d_ybsum.ptr, ctx->d_yboff.ptr, h_total));
     if (S_hint == 0) {
         VC_HIP(ctx, hipStreamSynchronize(st));
-        S_hint = *(ctx->h_xtotal + 1);
+        S_hint = *h_total;
     }
     if (S_hint > ctx->d_gathered.cap)            // survivor counts drift from frame to frame: grow with slack
         VC_TRY(ensure(ctx, ctx->d_gathered, (size_t)(S_hint + S_hint / 8 + 1024)));
@@ -964,7 +976,7 @@ int vc_destroy(vc_ctx *ctx)
         if (b.e_prep) (void)hipEventDestroy(b.e_prep);
     }
     release(ctx->d_viewmask); release(ctx->d_scratch); release(ctx->d_counts); release(ctx->d_gathered);
-    release(ctx->d_ent_all); release(ctx->d_xcnt); release(ctx->d_xoff); release(ctx->d_xbsum);
+    release(ctx->d_ent_all[0]); release(ctx->d_ent_all[1]); release(ctx->d_xcnt); release(ctx->d_xoff); release(ctx->d_xbsum);
     release(ctx->d_xboff); release(ctx->d_lut_color);
     release(ctx->d_ycnt); release(ctx->d_yoff); release(ctx->d_ybsum); release(ctx->d_yboff);
     if (ctx->h_xtotal) (void)hipHostFree(ctx->h_xtotal);
@@ -1968,7 +1980,7 @@ int vc_comm_destroy(vc_ctx *ctx)
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipStreamSynchronize(ctx->stream2);
-        ctx->gather_pending = false;
+        ctx->gpend[0] = ctx->gpend[1] = false;
         VC_NCCL(ctx, g_rccl.CommDestroy(ctx->comm));
         ctx->comm = nullptr;
     }
@@ -2009,10 +2021,10 @@ int vc_expand_entries(vc_ctx *ctx, const uint64_t *entries, uint64_t n_entries, 
     VC_TRY(finish_gather(ctx));
     ctx->gathered = false;
     VC_TRY(ensure_exchange_scratch(ctx, 1));
-    VC_TRY(ensure(ctx, ctx->d_ent_all, (size_t)(2 * n_entries)));
+    VC_TRY(ensure(ctx, ctx->d_ent_all[0], (size_t)(2 * n_entries)));
     if (n_entries)
-        VC_HIP(ctx, hipMemcpyAsync(ctx->d_ent_all.ptr, entries, n_entries * 2 * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-    VC_TRY(enqueue_expand(ctx, ctx->stream, ctx->d_ent_all.ptr, n_entries, 0));
+        VC_HIP(ctx, hipMemcpyAsync(ctx->d_ent_all[0].ptr, entries, n_entries * 2 * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    VC_TRY(enqueue_expand(ctx, ctx->stream, ctx->d_ent_all[0].ptr, n_entries, 0));
     VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->gathered_total = n_entries ? *(ctx->h_xtotal + 1) : 0;
     ctx->gathered = true;
@@ -2027,9 +2039,11 @@ static int allgather_compact(vc_ctx *ctx, uint64_t *counts_out, uint64_t *total_
 {
     const int G = ctx->n_ranks;
     StepBuf &cur = ctx->sb[ctx->cur];
-    VC_TRY(finish_gather(ctx));                                  // (the previous expansion still reads d_ent_all)
+    const uint32_t half = ctx->gseq & 1u;
+    VC_TRY(finish_one(ctx, half));                               // the gather before last owned this half; the last one may still run
+    DevBuf<uint64_t> &ent_all = ctx->d_ent_all[half];
     hipEvent_t *E = ctx->gx[ctx->gx_next];                       // this gather's own events: see vc_ctx::gx
-    ctx->gx_cur = ctx->gx_next;
+    ctx->gx_idx[half] = ctx->gx_next;
     ctx->gx_next = (ctx->gx_next + 1) % kGatherRing;
     VC_HIP(ctx, hipEventRecord(E[0], ctx->stream));
     if (!cur.counts_exchanged) {                 // vc_carve_begin did not do it (records were kept)
@@ -2039,14 +2053,14 @@ static int allgather_compact(vc_ctx *ctx, uint64_t *counts_out, uint64_t *total_
     }
     uint64_t M = 0, S = 0;
     for (int r = 0; r < G; ++r) { M += cur.h_counts[2 * r]; S += cur.h_counts[2 * r + 1]; }
-    if (2 * M > ctx->d_ent_all.cap) VC_TRY(ensure(ctx, ctx->d_ent_all, (size_t)(2 * M + M / 4 + 1024)));
+    if (2 * M > ent_all.cap) VC_TRY(ensure(ctx, ent_all, (size_t)(2 * M + M / 4 + 1024)));
     VC_TRY(ensure(ctx, cur.ent, 2));
     VC_NCCL(ctx, g_rccl.GroupStart());
     uint64_t disp = 0;
     for (int r = 0; r < G; ++r) {
         const uint64_t cnt = cur.h_counts[2 * r];
         if (cnt) {
-            ncclResult_t rc = g_rccl.Broadcast(cur.ent.ptr, ctx->d_ent_all.ptr + 2 * disp, 2 * cnt, ncclUint64, r,
+            ncclResult_t rc = g_rccl.Broadcast(cur.ent.ptr, ent_all.ptr + 2 * disp, 2 * cnt, ncclUint64, r,
                                                ctx->comm, ctx->stream);
             if (rc != ncclSuccess) {
                 g_rccl.GroupEnd();
@@ -2060,15 +2074,16 @@ static int allgather_compact(vc_ctx *ctx, uint64_t *counts_out, uint64_t *total_
     // the expansion runs beside the next step's carve (second stream) when the call does not wait for it anyway
     hipStream_t xs = (ctx->overlap && !ctx->gather_sync) ? ctx->stream2 : ctx->stream;
     if (xs != ctx->stream) VC_HIP(ctx, hipStreamWaitEvent(xs, E[2], 0));
-    if (S) VC_TRY(enqueue_expand(ctx, xs, ctx->d_ent_all.ptr, M, S));
+    if (S) VC_TRY(enqueue_expand(ctx, xs, ent_all.ptr, M, S, ctx->h_xtotal + 2 + half));
     VC_HIP(ctx, hipEventRecord(E[1], xs));
     if (S && cur.color_cam >= 0 && xs != ctx->stream) {          // the expansion reads the slot's bits / images beside the carve stream
         Slot &sl = ctx->slots[cur.slot];
         sl.e_emit = E[1];
         sl.emit_pending = true;
     }
-    ctx->gather_pending = true;
-    ctx->gather_expect = S;
+    ctx->gpend[half] = true;
+    ctx->gexpect[half] = S;
+    ctx->gseq++;
     if (counts_out) for (int r = 0; r < G; ++r) counts_out[r] = cur.h_counts[2 * r + 1];
     ctx->gathered_total = S;
     ctx->gathered = true;
