@@ -217,7 +217,8 @@ int vc_fetch_mesh(vc_ctx *ctx, float *verts, uint32_t *faces);
  *   timing          timing_detail (0)  1: vc_carve_begin steps record the events around preparation and carve kernels too
  *                                  (vc_carve always does; see vc_timing_t)
  *   multi-GPU       gather_compact (1)  exchange occupancy words instead of records;
- *                   gather_sync (1)  0: vc_allgather returns once its work is queued
+ *                   gather_sync (1)  0: vc_allgather returns once its work is queued (two gathers may be in flight; a read-back,
+ *                                  vc_timing or vc_synchronize waits for them; vc_fetch_gathered returns the last one's list)
  * Unknown names or out-of-range values return VC_ERR_ARG. */
 int vc_set_option(vc_ctx *ctx, const char *name, int value);
 int vc_timing(vc_ctx *ctx, vc_timing_t *out);
