@@ -54,8 +54,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--prewarm-seconds", type=float, default=1.0,
                     help="untimed launches before the W warm-up steps so the clocks have ramped")
-    ap.add_argument("--depth", type=int, choices=(1, 2), default=2,
-                    help="steps in flight: with 2, step i+1 is queued on the device before the host collects step i")
+    ap.add_argument("--depth", type=int, choices=(1, 2, 3), default=3,
+                    help="steps in flight: step i+1 (and i+2) are queued on the device before the host collects step i")
     ap.add_argument("--transport", choices=("rccl", "host"), default="rccl",
                     help="N>1 survivor exchange: rccl (device, default) or host (gloo; rehearsal on one GPU)")
     ap.add_argument("--allow-host-fallback", action="store_true",
@@ -157,7 +157,7 @@ def make_workload(args):
     return (G, G, G), cams, masks, frames, 1, "lut", "%d^3 voxel grid x the reference's 4 calibrated cameras" % G
 
 
-def run_mode(eng, grp, mode, steps, warmup, multi, host_transport=None, depth=2, exchange="compact", overlap=1, fresh=True,
+def run_mode(eng, grp, mode, steps, warmup, multi, host_transport=None, depth=3, exchange="compact", overlap=1, fresh=True,
              detail=False, cc=1):
     """W untimed + K timed steps of one mode; returns (seconds, survivors of this rank, total, timing dict).
     overlap: the scan + record expansion of a step on a second stream, beside the next step's carve (the product's
@@ -199,19 +199,25 @@ def run_mode(eng, grp, mode, steps, warmup, multi, host_transport=None, depth=2,
         eng.carve_begin(slot=slot, mode=mode, records=keep, color_cam=cc)
 
     def run(first, count):
-        """`count` steps; with depth 2 step i+1 is enqueued before step i is collected, so the device
-        never idles between steps."""
+        """`count` steps, `depth` of them in flight: step i+1 (and i+2) are enqueued before step i is collected, so the
+        device never idles between steps."""
         last = (0, 0)
         if depth <= 1:
             for i in range(count):
                 begin(first + i)
                 last = finish()
             return last
-        begin(first)
-        for i in range(1, count):
+        pending = 0
+        for i in range(count):
             begin(first + i)
+            pending += 1
+            if pending == depth:
+                last = finish()
+                pending -= 1
+        while pending:
             last = finish()
-        return finish()
+            pending -= 1
+        return last
 
     if warmup:
         run(0, warmup)

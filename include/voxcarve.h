@@ -149,11 +149,12 @@ int vc_project(vc_ctx *ctx, uint32_t cam, const double *xyz, uint64_t n, double 
 int vc_carve(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int mode,
              uint32_t flags, uint64_t *n_out);
 /* The same step split in two so that step i+1 is queued on the device before the host collects
- * step i (no idle gap between steps).  At most two steps may be in flight;
- * vc_carve_end completes the OLDEST one, whose records are then what vc_fetch_* / vc_allgather
- * read.  The two steps alternate between two sets of result buffers: with another step already in flight, the NEXT
- * vc_carve_begin is queued into the set that holds the collected result, so fetch it before that call -- afterwards
- * the vc_fetch_* functions fail with VC_ERR_ARG until the next vc_carve_end.
+ * step i (no idle gap between steps).  At most THREE steps may be in flight (with two, the host cannot queue step i + 1
+ * before it has collected step i - 1, whose record expansion ends about when the carve of step i does: the carve stream would
+ * idle for the host's round trip); vc_carve_end completes the OLDEST one, whose records are then what vc_fetch_* /
+ * vc_allgather read.  The steps rotate through three sets of result buffers: a vc_carve_begin that is queued into the set
+ * holding the collected result (the third one after it was issued) takes it away -- fetch before that call; afterwards the
+ * vc_fetch_* functions fail with VC_ERR_ARG until the next vc_carve_end.
  * min_views > n_cameras is legal and yields the empty result (as the reference's threshold test would). */
 int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int mode, uint32_t flags);
 int vc_carve_end(vc_ctx *ctx, uint64_t *n_out);

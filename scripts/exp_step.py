@@ -26,12 +26,16 @@ for s in range(4):
     eng.upload_frame(1, np.roll(frames[1], 3 * s, axis=1), slot=s)
 if mode == "lut":
     eng.build_lut()
+depth = int(os.environ.get("DEPTH", "2"))
 def run(n):
-    eng.carve_begin(slot=0, mode=mode)
-    for i in range(1, n):
+    pending = 0
+    for i in range(n):
         eng.carve_begin(slot=i % 4, mode=mode)
-        eng.carve_end()
-    eng.carve_end()
+        pending += 1
+        if pending == depth:
+            eng.carve_end(); pending -= 1
+    while pending:
+        eng.carve_end(); pending -= 1
     eng.synchronize()
 run(30)
 best = 1e9

@@ -528,19 +528,22 @@ def voxcarve_unpack(rec):
 
 
 def test_fetch_after_the_result_buffers_were_reissued_fails(eng, cams, masks, frames):
-    """begin A, begin B, end (-> A collected), begin C: C is queued into A's buffers, so A can no longer be
-    fetched -- an error, never a mix of two steps."""
+    """Three sets of result buffers: begin A, begin B, end (-> A collected), begin C (third set: A still there), begin D:
+    D is queued into A's buffers, so A can no longer be fetched -- an error, never a mix of two steps."""
     from voxcarve._lib import VoxcarveError
     setup_real(eng, cams, masks, frames, (64, 64, 64))
     eng.carve_begin()
     eng.carve_begin()
     n = eng.carve_end()
+    assert eng.fetch_records().size == n                        # A's records
+    eng.carve_begin()
     assert eng.fetch_records().size == n                        # still A's records
     eng.carve_begin()
     for f in (eng.fetch_records, eng.fetch, eng.fetch_occupancy, eng.pack_entries):
         with pytest.raises(VoxcarveError, match="no carve result"):
             f()
     assert eng.carve_end() == n and eng.fetch_records().size == n
+    assert eng.carve_end() == n
     assert eng.carve_end() == n
 
 
@@ -561,7 +564,7 @@ def test_threshold_above_camera_count_is_empty_on_every_path(eng, cams, masks, f
 
 
 def test_overlapped_steps_begin_end(eng, cams, masks, frames):
-    """Two steps in flight (step i+1 queued before step i is collected) give the records of the
+    """Two and three steps in flight (step i+1, i+2 queued before step i is collected) give the records of the
     one-at-a-time calls, in order, for both modes."""
     from voxcarve._lib import VoxcarveError
     grid = (128, 128, 128)
@@ -590,12 +593,26 @@ def test_overlapped_steps_begin_end(eng, cams, masks, frames):
             assert np.array_equal(a, b)
         with pytest.raises(VoxcarveError, match="no carve step"):
             eng.carve_end()
-    eng.carve_begin(slot=0)
-    eng.carve_begin(slot=1)
-    with pytest.raises(VoxcarveError, match="already in flight"):
-        eng.carve_begin(slot=0)
-    eng.carve_end()
-    eng.carve_end()
+    # three steps in flight, collected in order; a fourth is refused
+    for mode in ("lut", "fused"):
+        want = []
+        for slot in (0, 1, 0, 1, 1):
+            eng.carve(slot=slot, mode=mode)
+            want.append(eng.fetch_records())
+        got = []
+        for slot in (0, 1, 0):
+            eng.carve_begin(slot=slot, mode=mode)
+        with pytest.raises(VoxcarveError, match="already in flight"):
+            eng.carve_begin(slot=0, mode=mode)
+        for slot in (1, 1):
+            assert eng.carve_end() == want[len(got)].size
+            got.append(eng.fetch_records())
+            eng.carve_begin(slot=slot, mode=mode)
+        for _ in range(3):
+            assert eng.carve_end() == want[len(got)].size
+            got.append(eng.fetch_records())
+        for a_, b_ in zip(got, want):
+            assert np.array_equal(a_, b_), mode
 
 
 @pytest.mark.parametrize("grid", [(64, 64, 64), (33, 31, 20), (128, 64, 96)])

@@ -150,7 +150,8 @@ struct StepBuf {
     DevBuf<uint64_t> blocksum, blockoff;     // blockoff[nscan] = total
     DevBuf<uint64_t> records;
     uint64_t *h_total = nullptr;             // pinned
-    hipEvent_t e0 = nullptr, e_first = nullptr, e1 = nullptr, e2 = nullptr, e_scan = nullptr, e_prep = nullptr;
+    hipEvent_t e0 = nullptr, e_first = nullptr, e1 = nullptr, e_prep = nullptr;
+    hipEvent_t e2 = nullptr, e_scan = nullptr;   // borrowed from vc_ctx::step_ev for the step in this set (see there)
     bool prepped = false, prep_timed = false; // this step queued preparation kernels in front of its carve (timed: e_prep .. e0)
     bool carve_timed = false;                // e0 / e1 were recorded around the carve kernels (synchronous calls, timing_detail)
     bool emit_timed = false;                 // e_scan / e2 bracket the record expansion
@@ -170,6 +171,10 @@ struct StepBuf {
     uint64_t n = 0, survivors = 0;
 };
 
+constexpr int kDepth = 3;                   // sets of result buffers = carve steps that may be in flight: with two, the host cannot queue step i + 1
+                                            // before it has collected step i - 1, whose expansion ends when the carve of step i does -- the carve
+                                            // stream then idles for the host's round trip (20 us of a 155 us step)
+constexpr uint32_t kStepRing = 64;
 constexpr uint32_t kGatherRing = 32;        // steps before a gather's events are recorded again (more than the resident frame sets a stream cycles through)
 struct vc_ctx {
     int device = 0;
@@ -179,13 +184,17 @@ struct vc_ctx {
     hipEvent_t ev_h[2] = {nullptr, nullptr};   // around the last mask upload (h2d_ms)
     bool h2d_pending = false;
     int overlap = 1;                 // (one stream when a communicator is attached: its collectives order everything)
-    StepBuf sb[2];
+    StepBuf sb[kDepth];
     int head = 0, npending = 0, cur = -1;    // next set to issue into, steps in flight, set holding the fetched result
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // the compact all-gather's events {start, expansion done, payload arrived}, a RING of them: a frame set's next preparation
     // waits for the expansion that read it (Slot::e_emit), many steps later -- one event re-recorded every step would make it
     // wait for the newest expansion instead and put carve, exchange, expansion and preparation in one line
     hipEvent_t gx[kGatherRing][3] = {};
+    // the same for a step's {scan done, step done}: frame sets remember them (Slot::e_carve, e_emit) for their next preparation,
+    // kStepRing steps of distance keep that wait on the step that read the frame set and not on a newer one
+    hipEvent_t step_ev[kStepRing][2] = {};
+    uint32_t step_next = 0;
     uint32_t gx_next = 0;
     std::string err;
 
@@ -916,19 +925,19 @@ int vc_create(int device, vc_ctx **out)
     if (e1 == hipSuccess) e1 = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
     if (e1 == hipSuccess) e1 = hipStreamCreateWithFlags(&ctx->stream_up, hipStreamNonBlocking);
     for (int k = 0; k < 2 && e1 == hipSuccess; ++k) e1 = hipEventCreate(&ctx->ev_h[k]);
-    for (int k = 0; k < 2 && e1 == hipSuccess; ++k) {
+    for (int k = 0; k < kDepth && e1 == hipSuccess; ++k) {
         StepBuf &b = ctx->sb[k];
         e1 = hipEventCreate(&b.e0);
         if (e1 == hipSuccess) e1 = hipEventCreate(&b.e_first);
         if (e1 == hipSuccess) e1 = hipEventCreate(&b.e1);
-        if (e1 == hipSuccess) e1 = hipEventCreate(&b.e2);
-        if (e1 == hipSuccess) e1 = hipEventCreate(&b.e_scan);
             if (e1 == hipSuccess) e1 = hipEventCreate(&b.e_prep);
         if (e1 == hipSuccess) e1 = hipHostMalloc(reinterpret_cast<void **>(&b.h_total), sizeof(uint64_t), hipHostMallocDefault);
     }
     for (int i = 0; i < 4 && e1 == hipSuccess; ++i) e1 = hipEventCreate(&ctx->ev[i]);
     for (uint32_t r = 0; r < kGatherRing && e1 == hipSuccess; ++r)
         for (int i = 0; i < 3 && e1 == hipSuccess; ++i) e1 = hipEventCreate(&ctx->gx[r][i]);
+    for (uint32_t r = 0; r < kStepRing && e1 == hipSuccess; ++r)
+        for (int i = 0; i < 2 && e1 == hipSuccess; ++i) e1 = hipEventCreate(&ctx->step_ev[r][i]);
     if (e1 == hipSuccess) e1 = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_total), sizeof(uint64_t), hipHostMallocDefault);
     const char *fg = getenv("VOXCARVE_FORCE_GENERIC");
     ctx->force_generic = fg && fg[0] == '1';
@@ -958,6 +967,8 @@ int vc_destroy(vc_ctx *ctx)
     for (int k = 0; k < 2; ++k) if (ctx->ev_h[k]) (void)hipEventDestroy(ctx->ev_h[k]);
     for (uint32_t r = 0; r < kGatherRing; ++r)
         for (int i = 0; i < 3; ++i) if (ctx->gx[r][i]) (void)hipEventDestroy(ctx->gx[r][i]);
+    for (uint32_t r = 0; r < kStepRing; ++r)
+        for (int i = 0; i < 2; ++i) if (ctx->step_ev[r][i]) (void)hipEventDestroy(ctx->step_ev[r][i]);
     release(ctx->d_axes); release(ctx->d_morph); release(ctx->d_lut); release(ctx->d_bbox); release(ctx->d_lut_tile); release(ctx->d_tbox); release(ctx->d_kbox); release(ctx->d_live); release(ctx->d_wbox); release(ctx->d_bm); release(ctx->d_blist); release(ctx->d_wlist);
     release(ctx->d_mcbits); release(ctx->d_mcx); release(ctx->d_mcwbase); release(ctx->d_mcgv); release(ctx->d_mcgt); release(ctx->d_mcgvoff);
     release(ctx->d_mcgtoff); release(ctx->d_mcfaces); release(ctx->d_mcbv); release(ctx->d_mcbvoff); release(ctx->d_mcbt); release(ctx->d_mcbtoff);
@@ -971,8 +982,6 @@ int vc_destroy(vc_ctx *ctx)
         if (b.e0) (void)hipEventDestroy(b.e0);
         if (b.e_first) (void)hipEventDestroy(b.e_first);
         if (b.e1) (void)hipEventDestroy(b.e1);
-        if (b.e2) (void)hipEventDestroy(b.e2);
-        if (b.e_scan) (void)hipEventDestroy(b.e_scan);
         if (b.e_prep) (void)hipEventDestroy(b.e_prep);
     }
     release(ctx->d_viewmask); release(ctx->d_scratch); release(ctx->d_counts); release(ctx->d_gathered);
@@ -1328,7 +1337,7 @@ int vc_project(vc_ctx *ctx, uint32_t cam, const double *xyz, uint64_t n, double 
 int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam, int mode, uint32_t flags)
 {
     if (!ctx) return VC_ERR_ARG;
-    if (ctx->npending >= 2) return fail(ctx, VC_ERR_ARG, "two carve steps are already in flight: call vc_carve_end");
+    if (ctx->npending >= kDepth) return fail(ctx, VC_ERR_ARG, "%d carve steps are already in flight: call vc_carve_end", kDepth);
     if (!ctx->have_grid || !ctx->have_cams) return fail(ctx, VC_ERR_ARG, "grid and cameras must be set before vc_carve");
     if (slot >= ctx->slots.size() || !ctx->slots[slot].have_masks)
         return fail(ctx, VC_ERR_ARG, "no masks uploaded in slot %u", slot);
@@ -1347,6 +1356,9 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
         ctx->carved = false; ctx->viewmask_valid = false; ctx->packed = false;
     }
     StepBuf &sb = ctx->sb[ctx->head];
+    sb.e_scan = ctx->step_ev[ctx->step_next][0];
+    sb.e2 = ctx->step_ev[ctx->step_next][1];
+    ctx->step_next = (ctx->step_next + 1) % kStepRing;
     sb.n = n; sb.survivors = 0; sb.want_vm = want_vm; sb.has_first = false;
     sb.allseen = min_views == ctx->C;
     sb.no_records = (flags & VC_FLAG_NO_RECORDS) != 0;
@@ -1363,7 +1375,7 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
             VC_HIP(ctx, hipEventRecord(sb.e2, ctx->stream));
             sb.counts_exchanged = true;
         }
-        sb.pending = true; sb.used = false; ctx->head ^= 1; ctx->npending++;
+        sb.pending = true; sb.used = false; ctx->head = (ctx->head + 1) % kDepth; ctx->npending++;
         return VC_OK;
     }
 
@@ -1615,7 +1627,7 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     if (!s.carve_pending) { s.e_carve = sb.e2; s.carve_pending = true; }                       // (no e_scan recorded: e2 is behind the carve kernels too)
     sb.pending = true;
     sb.used = true;
-    ctx->head ^= 1;
+    ctx->head = (ctx->head + 1) % kDepth;
     ctx->npending++;
     return VC_OK;
 }
@@ -1628,7 +1640,7 @@ int vc_carve_end(vc_ctx *ctx, uint64_t *n_out)
     *n_out = 0;
     if (ctx->npending == 0) return fail(ctx, VC_ERR_ARG, "no carve step in flight");
     VC_HIP(ctx, hipSetDevice(ctx->device));
-    const int k = (ctx->npending == 2) ? ctx->head : (ctx->head ^ 1);      // oldest pending set
+    const int k = (ctx->head - ctx->npending + kDepth) % kDepth;           // oldest pending set
     StepBuf &sb = ctx->sb[k];
     ctx->carved = false; ctx->viewmask_valid = false; ctx->gathered = false; ctx->packed = false;
     if (sb.n != 0) {
