@@ -2247,7 +2247,9 @@ __device__ __forceinline__ void emit_prepare(const EmitParams &p, uint64_t &nz, 
 #pragma unroll
     for (int b = 0; b < EB; ++b) {
         B.off[b] = -1;
-        if (p.has_cam && ((B.wv[b] >> lane) & 1ull)) {
+        // (the word's bits, wave-uniform, ARE the lane mask of "my voxel survives": handed to the compiler as such, the branch is
+        // one s_and_saveexec instead of shift, and, compare per lane)
+        if (p.has_cam && __builtin_amdgcn_inverse_ballot_w64(B.wv[b])) {
             const uint32_t j = (INDIRECT ? B.jb[b] : (uint32_t)((gw + (B.wl[b] >> 16)) << 6)) + lane;
             if (FROM_LUT) {
                 // (tile order: the word starts at a multiple of 64 and ny % 64 == 0, so its 64 voxels are 4 runs of 16 entries;
@@ -2298,7 +2300,7 @@ __device__ __forceinline__ void emit_finish(const EmitParams &p, uint64_t out0, 
     }
 #pragma unroll
     for (int b = 0; b < EB; ++b) {
-        if ((B.wv[b] >> lane) & 1ull) {
+        if (__builtin_amdgcn_inverse_ballot_w64(B.wv[b])) {
             const uint64_t o = out0 + (B.wl[b] & 0xffffu) + (uint32_t)__popcll(B.wv[b] & below);
             // (streamed past the caches: 238 MB per step that nothing on the device reads again would evict the masks, images
             // and block grids the next kernels want)
