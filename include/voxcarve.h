@@ -110,7 +110,7 @@ int vc_set_cameras(vc_ctx *ctx, uint32_t n_cameras, const double *K9, const doub
  * on first use).  ASYNCHRONOUS: the bytes are copied to a page-locked staging buffer and from there to the device
  * on an upload stream of their own, so the call returns at once and the copy runs beside the carve in flight; the
  * caller's buffer is free when the call returns.  Everything derived from the bytes (bit masks, foreground boxes,
- * cropped block grids, camera visiting order, BGRX images) is made ON THE DEVICE by two kernels queued in front of
+ * cropped block grids, camera visiting order, images in the records' byte order) is made ON THE DEVICE by two kernels queued in front of
  * the first vc_carve / vc_carve_begin that uses the slot -- no host round trip anywhere. */
 int vc_upload_masks(vc_ctx *ctx, uint32_t slot, const uint8_t *masks);
 /* The byte masks and images resident in `slot` are to be taken as NEW input: the next carve on the slot derives

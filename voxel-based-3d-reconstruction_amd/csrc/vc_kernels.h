@@ -29,6 +29,7 @@
 namespace vc {
 
 constexpr uint32_t kBlock = 256;            // 4 wavefronts
+constexpr uint32_t kSeenFlag = 1u << 24;    // bit 56 of a record: the colour camera sees the voxel
 constexpr uint32_t kGroupWords = 64;        // compaction group = 64 words = 4096 voxels (one word per lane)
 constexpr uint32_t kScanBlock = 1024;       // groups per scan workgroup
 constexpr uint32_t kMaxCameras = 16;
@@ -146,7 +147,8 @@ struct CarveParams {
 struct EmitParams {
     const double *xs, *ys, *zs;
     const uint32_t *maskbits;   // colour camera's mask bits (or null)
-    const uint32_t *frame;      // colour camera's image as one BGRX dword per pixel (or null)
+    const uint32_t *frame;      // colour camera's image as one dword per pixel, laid out as the upper half of a record: R | G << 8 |
+                                // B << 16 | seen << 24 (or null)
     const int32_t *lut;         // colour camera's packed table (FROM_LUT), else null
     uint32_t lut_tq;            // != 0: that table is in TILE order (tile words per row quad = ny / 16); 0: y-major
     const uint64_t *words;
@@ -1523,7 +1525,7 @@ __global__ __launch_bounds__(kBlock) void k_assemble(const CarveParams p, const 
 // voxel_reconstruction.py:89, are already on the device).  All of it lands in the frame set's header.
 //
 //  k_prep_pack  byte masks -> bit masks (foreground where byte > 0, voxel_reconstruction.py:112) for all cameras,
-//               BGR images -> one BGRX dword per pixel (a colour sample is then a single aligned load), and each
+//               BGR images -> one dword per pixel in the layout of a record's upper half (a colour sample is then a single aligned load, no byte swap), and each
 //               camera's foreground pixel bounding box: workgroup reduction, then atomics only where they still move
 //               the box.  The boxes are double-buffered by the slot's frame parity: this launch fills one set and
 //               empties the other for the next frame, so no memset (and no fence) sits anywhere.
@@ -1537,7 +1539,7 @@ __global__ __launch_bounds__(kBlock) void k_assemble(const CarveParams p, const 
 struct PrepParams {
     const uint8_t *src[kMaxCameras];   // byte mask of each camera (as uploaded, or post-filtered)
     const uint8_t *fsrc[kMaxCameras];  // BGR images to expand (nframes of them) ...
-    uint32_t *fdst[kMaxCameras];       // ... into BGRX
+    uint32_t *fdst[kMaxCameras];       // ... into R | G << 8 | B << 16 | seen << 24
     uint32_t *bits;                    // [C][mwords]
     uint32_t *grid;                    // the frame set's header + grids
     uint32_t *boxes;                   // [2][kMaxCameras][kBoxStride] foreground boxes
@@ -1625,15 +1627,17 @@ __global__ __launch_bounds__(kBlock) void k_prep_pack(const PrepParams p)
         if (i4 + 4u <= p.HW) {
             const uint32_t *s4 = reinterpret_cast<const uint32_t *>(src) + 3u * t;
             const uint32_t w0 = s4[0], w1 = s4[1], w2 = s4[2];
+            // B G R bytes -> the upper half of a record as it is: R | G << 8 | B << 16 | "seen" << 24
+            const uint32_t x0 = w0 & 0xffffffu, x1 = (w0 >> 24) | ((w1 & 0xffffu) << 8), x2 = (w1 >> 16) | ((w2 & 0xffu) << 16), x3 = w2 >> 8;
             uint4 o;
-            o.x = w0 & 0xffffffu;
-            o.y = (w0 >> 24) | ((w1 & 0xffffu) << 8);
-            o.z = (w1 >> 16) | ((w2 & 0xffu) << 16);
-            o.w = w2 >> 8;
+            o.x = kSeenFlag | ((x0 & 0xffu) << 16) | (x0 & 0xff00u) | (x0 >> 16);
+            o.y = kSeenFlag | ((x1 & 0xffu) << 16) | (x1 & 0xff00u) | (x1 >> 16);
+            o.z = kSeenFlag | ((x2 & 0xffu) << 16) | (x2 & 0xff00u) | (x2 >> 16);
+            o.w = kSeenFlag | ((x3 & 0xffu) << 16) | (x3 & 0xff00u) | (x3 >> 16);
             reinterpret_cast<uint4 *>(dst)[t] = o;
         } else {
             for (uint32_t i = i4; i < p.HW; ++i)
-                dst[i] = (uint32_t)src[3 * i] | ((uint32_t)src[3 * i + 1] << 8) | ((uint32_t)src[3 * i + 2] << 16);
+                dst[i] = kSeenFlag | ((uint32_t)src[3 * i] << 16) | ((uint32_t)src[3 * i + 1] << 8) | (uint32_t)src[3 * i + 2];
         }
     }
 }
@@ -2187,8 +2191,8 @@ __device__ __forceinline__ void emit_body(const EmitParams &p, uint32_t vblock)
             for (int u = 0; u < EU; ++u) {
                 rec[u] = (uint32_t)(p.i0 + j[u]);
                 if (off[u] >= 0 && (ALLSEEN || (p.maskbits && mask_bit(p.maskbits, off[u])))) {
-                    const uint64_t px = p.frame ? (uint64_t)p.frame[off[u]] : 0ull;       // B | G<<8 | R<<16
-                    rec[u] |= ((px >> 16) & 0xffull) << 32 | ((px >> 8) & 0xffull) << 40 | (px & 0xffull) << 48 | (1ull << 56);
+                    const uint64_t px = p.frame ? (uint64_t)p.frame[off[u]] : (uint64_t)kSeenFlag;   // R | G<<8 | B<<16 | seen<<24
+                    rec[u] |= px << 32;
                 }
             }
 #pragma unroll
@@ -2288,15 +2292,14 @@ __device__ __forceinline__ void emit_finish(const EmitParams &p, uint64_t out0, 
 #pragma unroll
     for (int b = 0; b < EB; ++b) {
         seen[b] = B.off[b] >= 0 && (ALLSEEN || (p.maskbits && ((mw[b] >> ((uint32_t)B.off[b] & 31u)) & 1u)));
-        px[b] = 0u;
-        if (seen[b] && p.frame) px[b] = p.frame[B.off[b]];                          // B | G<<8 | R<<16
+        px[b] = kSeenFlag;
+        if (seen[b] && p.frame) px[b] = p.frame[B.off[b]];                          // R | G<<8 | B<<16 | seen<<24: a record's upper half
     }
     uint64_t rec[EB];
 #pragma unroll
     for (int b = 0; b < EB; ++b) {
         rec[b] = (uint32_t)(p.i0 + (INDIRECT ? B.jb[b] : (uint32_t)((gw + (B.wl[b] >> 16)) << 6)) + lane);
-        if (seen[b])
-            rec[b] |= (uint64_t)((px[b] >> 16) & 0xffu) << 32 | (uint64_t)((px[b] >> 8) & 0xffu) << 40 | (uint64_t)(px[b] & 0xffu) << 48 | (1ull << 56);
+        if (seen[b]) rec[b] |= (uint64_t)px[b] << 32;
     }
 #pragma unroll
     for (int b = 0; b < EB; ++b) {

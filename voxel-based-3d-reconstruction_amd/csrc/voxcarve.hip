@@ -87,7 +87,7 @@ struct DevBuf {
 };
 
 // One resident frame set.  The uploaded bytes stay on the device (bytes / fbytes), so the derived state (bit masks,
-// BGRX images, block grids, camera order -- all made on the device by k_prep_pack / k_prep_grid, queued in front of
+// record-layout images, block grids, camera order -- all made on the device by k_prep_pack / k_prep_grid, queued in front of
 // the first carve that uses the slot) can be re-derived without another transfer (vc_touch_masks).
 struct Slot {
     DevBuf<uint8_t> bytes;      // [C][H*W] byte masks as uploaded
@@ -96,10 +96,10 @@ struct Slot {
     DevBuf<uint8_t> fbytes[VC_MAX_CAMERAS];   // [H*W*3] BGR image of a camera as uploaded
     uint8_t *h_fbytes[VC_MAX_CAMERAS] = {nullptr};
     DevBuf<uint32_t> bits;      // [C][mwords]
-    DevBuf<uint32_t> frames;    // [C][H*W] BGRX, one dword per pixel
+    DevBuf<uint32_t> frames;    // [C][H*W] one dword per pixel: R | G << 8 | B << 16 | seen << 24 (a record's upper half)
     std::vector<uint8_t> have_frame, frame_dirty;
     bool have_masks = false;    // byte masks staged
-    bool bits_valid = false;    // bits, BGRX images and the grid plan match the staged bytes
+    bool bits_valid = false;    // bits, record-layout images and the grid plan match the staged bytes
     bool grids_valid = false;   // block grids and camera order too (they also depend on grid, slab and cameras)
     DevBuf<uint32_t> grid;      // header + cropped block grids of all cameras (hierarchical kernels stage it in LDS)
     DevBuf<uint32_t> coarse;    // the same with 4 x 4 times coarser blocks, for the brick level (frame sets with large grids only)
@@ -533,7 +533,7 @@ void release_slot(Slot &s)
 uint32_t grid_for(uint64_t n);
 
 // Queues, on the UPLOAD stream (behind the copy of the bytes it reads, beside the carve stream's work for the step before),
-// whatever the slot's derived state is missing: bit masks + BGRX images + grid plan (k_prep_pack, after the optional 2x2
+// whatever the slot's derived state is missing: bit masks + record-layout images + grid plan (k_prep_pack, after the optional 2x2
 // post-filter), and for the chunked / hierarchical kernels the block grids and the camera order (k_prep_grid).  No host
 // synchronisation: the kernels leave their results in the slot's header; e_prep marks their end for the carve stream.
 int ensure_prepared(vc_ctx *ctx, Slot &s, bool want_grids, const CarveParams *cp, bool timed = false, bool wide_ok = false)
@@ -1185,7 +1185,7 @@ int vc_upload_frame(vc_ctx *ctx, uint32_t slot, uint32_t cam, const uint8_t *bgr
     VC_TRY(stage_upload(ctx, *s, &s->h_fbytes[cam], nullptr, s->fbytes[cam].ptr, bgr, npix * 3, false));
     s->have_frame[cam] = 1;
     s->frame_dirty[cam] = 1;
-    s->bits_valid = false;           // the BGRX expansion rides in the same launch as the bit-packing
+    s->bits_valid = false;           // the image expansion rides in the same launch as the bit-packing
     return VC_OK;
 }
 
