@@ -2228,7 +2228,7 @@ struct EmitBatch {
 
 // takes the next (up to) EB non-zero words of the group off `nz` and starts their table loads (or projects)
 template <bool FROM_LUT, int EB, bool INDIRECT>
-__device__ __forceinline__ void emit_prepare(const EmitParams &p, uint64_t &nz, uint64_t mine, uint32_t mybase, uint32_t wstart,
+__device__ __forceinline__ void emit_prepare(const EmitParams &p, uint64_t &nz, uint64_t mine, uint32_t mybase, uint32_t &wstart,
                                              uint32_t tbase, uint64_t gw, uint32_t lane, EmitBatch<EB> &B,
                                              bool rowwords = false, uint32_t wix = 0, uint32_t wiy = 0, uint32_t wiz = 0)
 {
@@ -2244,7 +2244,10 @@ __device__ __forceinline__ void emit_prepare(const EmitParams &p, uint64_t &nz, 
             const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, (int)li);
             const uint32_t whi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), (int)li);
             B.wv[b] = ((uint64_t)whi << 32) | wlo;
-            B.wl[b] = (uint32_t)__builtin_amdgcn_readlane((int)wstart, (int)li) | (li << 16);
+            // (first record of the word inside the group = survivors of the words before it: they are taken in ascending order,
+            // so a running scalar sum does it -- no prefix scan over the group, no cross-lane read per word)
+            B.wl[b] = wstart | (li << 16);
+            wstart += (uint32_t)__popcll(B.wv[b]);
             tb[b] = (uint32_t)__builtin_amdgcn_readlane((int)tbase, (int)li);
         }
     }
@@ -2341,8 +2344,7 @@ template <bool FROM_LUT, bool ALLSEEN, int EB, bool INDIRECT>
 __device__ __forceinline__ void emit_group_lanes(const EmitParams &p, const uint32_t g, const uint32_t lane, const EmitGroup &h)
 {
     const uint64_t gw = (uint64_t)g * kGroupWords;
-    const uint32_t c = (uint32_t)__popcll(h.mine);
-    const uint32_t wstart = wave_inclusive_scan(c, lane) - c;           // first record of my word in the group
+    uint32_t wstart = 0;                                                // survivors of the group's words taken so far (wave-uniform)
     // colour look-up in a TILE-ordered table: where my word's 64 entries start (4 runs of 16; all lanes at once, once per group)
     const uint32_t tbase = (FROM_LUT && !INDIRECT && p.lut_tq) ? tile_index((uint32_t)((gw + lane) << 6), p.nx, p.ny, p.lut_tq) : 0u;
     uint64_t nz = __ballot(h.mine != 0);
