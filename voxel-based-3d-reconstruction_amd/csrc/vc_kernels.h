@@ -2364,10 +2364,12 @@ __device__ __forceinline__ void emit_group_lanes(const EmitParams &p, const uint
     }
     EmitBatch<EB> B;
     emit_prepare<FROM_LUT, EB, INDIRECT>(p, nz, h.mine, h.mybase, wstart, tbase, gw, lane, A);
-    while (A.any) {                                                     // wave-uniform
+    while (A.any) {                                                     // wave-uniform; A and B take turns (no copies)
         emit_prepare<FROM_LUT, EB, INDIRECT>(p, nz, h.mine, h.mybase, wstart, tbase, gw, lane, B);
         emit_finish<ALLSEEN, EB, INDIRECT>(p, h.out0, gw, lane, A);
-        A = B;
+        if (!B.any) break;
+        emit_prepare<FROM_LUT, EB, INDIRECT>(p, nz, h.mine, h.mybase, wstart, tbase, gw, lane, A);
+        emit_finish<ALLSEEN, EB, INDIRECT>(p, h.out0, gw, lane, B);
     }
 }
 
