@@ -302,7 +302,8 @@ def main():
     transport_note = ("rccl, %s" % ("non-zero occupancy words, expanded on every rank" if args.exchange == "compact"
                                     else "8-byte survivor records")) if multi else "none (one rank)"
     if multi and args.transport == "host":
-        host_transport = slabs.TorchTransport()
+        from torch_transport import TorchTransport      # tests/: the product package imports no framework
+        host_transport = TorchTransport()
         transport_note = "host (gloo) rehearsal"
     elif multi:
         # the decision "RCCL or not" is COLLECTIVE: every rank reports how its communicator set-up went through the

@@ -522,6 +522,37 @@ def test_stream_of_fresh_mask_sets_through_begin_end(eng, cams, masks, frames):
     assert np.array_equal(a, eng.fetch_records())
 
 
+def test_new_input_waits_for_every_step_that_reads_the_slot(eng, cams, masks, frames):
+    """Two records-free steps A, B in flight on ONE slot with no preparation between them, then new masks into that slot and a
+    third step C: the preparation for C overwrites the slot's bit masks and block grids and must wait for B's carve kernels, not
+    only for A's (a flag left set by A once kept A's event in place).  B's occupancy must be the oracle's for the OLD masks."""
+    from oracle import carve_c
+    grid = (256, 256, 256)
+    H, W = masks[0].shape
+    eng.set_grid(*grid)
+    eng.set_cameras(cams, H, W)
+    eng.build_lut()
+    oc = fx.oracle_cams(cams)
+    old_set = masks
+    new_set = [np.roll(m, 60, axis=1) for m in masks]
+    occ = {}
+    for name, ms in (("old", old_set), ("new", new_set)):
+        idx = carve_c.carve(*grid, oc, ms, frames)["idx"]
+        occ[name] = np.zeros(grid[0] * grid[1] * grid[2], bool)
+        occ[name][idx] = True
+    for mode in ("lut", "fused"):
+        for rnd in range(4):
+            eng.upload_masks(old_set, slot=0)
+            eng.upload_frame(1, frames[1], slot=0)
+            eng.carve_begin(slot=0, mode=mode, records=False)        # A (prepares the slot)
+            eng.carve_begin(slot=0, mode=mode, records=False)        # B (nothing to prepare)
+            eng.upload_masks(new_set, slot=0)
+            eng.carve_begin(slot=0, mode=mode, records=False)        # C (prepares again: behind B's kernels)
+            for name in ("old", "old", "new"):
+                eng.carve_end()
+                assert np.array_equal(eng.fetch_occupancy(), occ[name]), (mode, rnd, name)
+
+
 def voxcarve_unpack(rec):
     from voxcarve.engine import unpack_records
     return unpack_records(rec)
@@ -842,6 +873,48 @@ def test_lut_file_round_trip_and_rejection(eng, cams, masks, frames, tmp_path):
         eng.load_lut(path)
 
 
+@pytest.mark.parametrize("grid", [(50, 75, 20), (16, 256, 20), (8, 64, 12)])      # y-line words / brick pipeline / tile words
+def test_foreign_table_entries_outside_the_masks_count_as_minus_one(eng, cams, masks, frames, grid, tmp_path):
+    """vc_upload_lut: entries outside [-1, H*W) count as -1 on every table layout (the y-major table is rewritten in place,
+    the tile-ordered one while it is permuted), and -2 -- the per-voxel level's own "camera decided" sentinel -- is no
+    exception; CarveEngine.load_lut refuses a file that holds such values."""
+    from voxcarve._lib import VoxcarveError
+    setup_real(eng, cams, masks, frames, grid)
+    eng.build_lut()
+    tables = np.stack([eng.fetch_lut(c) for c in range(4)])
+    H, W = masks[0].shape
+    rng = np.random.default_rng(5)
+    dirty, clean = tables.copy(), tables.copy()
+    for c in range(4):
+        hit = rng.random(tables.shape[1]) < 0.02
+        vals = rng.choice(np.array([H * W, H * W + 12345, 2 ** 31 - 1, -2, -7, -2 ** 31], dtype=np.int64), size=int(hit.sum()))
+        dirty[c, hit] = vals.astype(np.int32)
+        clean[c, hit] = -1
+    eng.upload_lut(clean)
+    want = eng.carve(mode="lut")
+    rec = eng.fetch_records()
+    eng.upload_lut(dirty)
+    for opts in ({}, {"lut_hier": 0}, {"force_generic": 1}, {"lut_tile": 0}, {"bricks": 0}):
+        for k, v in opts.items():
+            eng.set_option(k, v)
+        try:
+            assert eng.carve(mode="lut") == want and np.array_equal(eng.fetch_records(), rec), (grid, opts)
+        finally:
+            for k in opts:
+                eng.set_option(k, {"lut_hier": 1, "force_generic": 0, "lut_tile": 1, "bricks": 1}[k])
+    assert np.array_equal(np.stack([eng.fetch_lut(c) for c in range(4)]), clean)
+    # the file form: a table with such entries is refused before it reaches the device
+    eng.build_lut()
+    path = str(tmp_path / "lut.npz")
+    eng.save_lut(path)
+    with np.load(path) as z:
+        lut, meta = z["lut"].copy(), z["meta"].copy()
+    lut[1, 17] = H * W
+    np.savez(path, lut=lut, meta=meta)
+    with pytest.raises(VoxcarveError, match="outside"):
+        eng.load_lut(path)
+
+
 def test_marching_cubes_on_device_equals_restatement(eng, cams, masks, frames):
     """the HIP marching cubes against oracle/marching_np.extract, vertex for vertex and face for face: volumes
     whose size is no multiple of 64 (words straddle rows and slabs), degenerate shapes, noise (every ambiguous case), both
@@ -1021,89 +1094,6 @@ def test_index_width_at_the_u32_limit(eng, cams, masks, frames):
         eng.set_grid(2048, 2048, 1024)                         # 2^32 voxels: refused
 
 
-def _run_bench(args, nproc=1, timeout=300, expect_rc=None):
-    """bench.py in a child process (as the driver launches it); returns the parsed JSON line of rank 0."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable]
-    if nproc > 1:
-        import socket
-        sock = socket.socket()
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-        sock.close()
-        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
-                "--master-port", str(port)]
-    cmd += [os.path.join(root, "bench.py"), "--gpus", str(nproc)] + args
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=root)
-    if expect_rc is not None:
-        assert out.returncode != 0, "bench.py was expected to fail"
-        return out
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    return json.loads(lines[0])
-
-
-def test_bench_contract_single_gpu(built):
-    """The JSON line the driver reads: keys, types, and the numbers that must hang together."""
-    d = _run_bench(["--grid", "256", "--steps", "7", "--warmup", "2", "--cpu-seconds", "1"])   # last step lands on frame set 0
-    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
-        assert key in d, key
-    assert d["n_gpus"] == 1 and d["steps"] == 7 and d["warmup"] == 2 and d["higher_is_better"] is True and d["vs_baseline"] is None
-    assert d["unit"] == "Mvoxel-views/s" and "workload" in d["config"] and "model" not in d["config"]
-    vv = 256 ** 3 * 4
-    assert abs(d["value"] - vv / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.02
-    r = d["roofline"]
-    assert r["bound"] in ("hbm", "mfma", "valu_f64") and r["peak"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
-    assert d["config"]["survivors"] == 461113                      # the 256^3 golden count: the bench ran the real path
-    assert r["frac"] <= 1.0 and "k_emit_busy" in r["kernel"] and r["avg_launch_ms"] > 0
-    assert d["contract_skip"]["skip_factor_vs_hbm_peak"] > 0
-    # the device's record list of frame set 0 is the CPU oracle's, byte for byte (the baseline leg carved the whole grid)
-    assert c["device_records_match"] is True and c["records_sha256"] == d["config"]["records_sha256_frame_set_0"]
-    assert d["config"]["survivors_frame_set_0"] == 461113 and d["config"]["ranks_agree_on_records"] is True
-    # every timed step prepared its frame set on the device, inside the timed region; the PCIe-inclusive figure is there
-    ph = d["phases_ms"]
-    # (the prep / carve figures come from a side run with extra events and from kernels that run beside other streams' kernels:
-    # at 256^3 they are of the order of the step itself, so only their order of magnitude is checked)
-    assert ph["steps_that_prepared"] == 7 and 0 < ph["frame_set_prep_on_device"] < 3 * d["ms_per_step"]
-    assert 0 < ph["carve_kernels"] < 3 * d["ms_per_step"] and ph["record_expansion"] > 0
-    assert d["pcie_inclusive"]["value"] > 0 and d["pcie_inclusive"]["value"] < d["value"]
-
-
-def test_bench_two_ranks_host_transport(built):
-    """The N > 1 flow of bench.py (work-balanced slab bounds, records-free steps, compact word exchange, expansion of
-    all ranks' words on the device) with two processes sharing this GPU; the exchange itself goes through gloo
-    because RCCL refuses two ranks on one device.  The gathered list must be the single-rank one."""
-    d = _run_bench(["--grid", "256", "--steps", "8", "--warmup", "1", "--no-cpu-baseline", "--single-device",
-                    "--transport", "host"], nproc=2, timeout=600)
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["cpu_baseline"] is None
-    assert "balanced" in d["config"]["split"] and "host" in d["config"]["exchange"]
-    # frame sets are rolled per step: the last timed step (index warmup + steps - 1 = 8 -> slot 0) is the unrolled set
-    assert d["config"]["survivors"] == 461113
-    for m in d["other_modes"].values():
-        assert m["survivors"] == 461113
-    assert d["config"]["ranks_agree_on_records"] is True and d["config"]["survivors_frame_set_0"] == 461113
-    assert d["config"]["rccl_ranks"] == 0
-
-
-def test_bench_rccl_failure_is_collective_and_loud(built):
-    """Two ranks on ONE device: RCCL refuses the duplicate device.  Without --allow-host-fallback every rank exits non-zero
-    (no JSON line, no silently different transport); with it the run completes on the /dev/shm transport and says so."""
-    out = _run_bench(["--grid", "256", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--single-device", "--only-headline"],
-                     nproc=2, timeout=600, expect_rc=True)
-    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert "RCCL communicator unavailable" in out.stderr
-    d = _run_bench(["--grid", "256", "--steps", "8", "--warmup", "1", "--no-cpu-baseline", "--single-device", "--only-headline",
-                    "--allow-host-fallback"], nproc=2, timeout=600)
-    assert "shm-fallback" in d["config"]["exchange"] and d["config"]["rccl_ranks"] == 0
-    assert d["config"]["survivors"] == 461113 and d["config"]["ranks_agree_on_records"] is True
-
-
 def test_property_random_shapes_cameras_masks(eng):
     """Property test (hypothesis, derandomised): for drawn grid shapes (tile-eligible or not), camera counts, mask
     sizes, foreground structure (noise / one blob / empty / full) and thresholds, both device modes give the
@@ -1153,20 +1143,3 @@ def test_property_random_shapes_cameras_masks(eng):
             eng.set_option("grid_lds_kb", 0)
 
     check()
-
-
-def test_bench_two_ranks_two_devices_over_rccl(built):
-    """The real N > 1 path -- one rank per GPU, RCCL communicator over two devices, grouped per-root broadcasts, expansion of
-    all ranks' words on every rank: needs a box with at least two GPUs (gpurun boxes have one: skipped there; the driver's
-    8-GPU scaling run exercises the same code).  Every rank must hold the committed, oracle-checked record list."""
-    import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
-    n = ctypes.c_int(0)
-    hip.hipGetDeviceCount(ctypes.byref(n))
-    if n.value < 2:
-        pytest.skip("one GPU on this box")
-    d = _run_bench(["--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--only-headline"], nproc=2, timeout=900)
-    c = d["config"]
-    assert d["n_gpus"] == 2 and c["rccl_ranks"] == 2 and c["exchange"].startswith("rccl")
-    assert c["ranks_agree_on_records"] is True and c["matches_committed_digest"] is True
-    assert c["survivors_frame_set_0"] == 29802555 and sum(c["survivors_per_rank"]) == 29802555

@@ -3,7 +3,6 @@
 The per-rank carve is stood in for by the oracle (this is a test of the partition and
 exchange logic of voxcarve.slabs, which on GPUs runs over RCCL inside libvoxcarve)."""
 import os
-import socket
 
 import numpy as np
 import pytest
@@ -11,12 +10,33 @@ import pytest
 import fixtures_util as fx
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
+def _launch_key():
+    """A number that stands in for MASTER_PORT where it is only a KEY of the launch directory (no socket is opened on it)."""
+    return 20000 + os.getpid() % 20000
+
+
+def _init_gloo(rank, world, out_dir):
+    """Process group without a pre-probed port: rank 0 listens on port 0 (the kernel picks a free one) and publishes the
+    number through the test's directory; the others connect to it.  Probing a port, closing it and handing the number to
+    someone who listens later leaves a window for EADDRINUSE (GPUTEST_r02)."""
+    import time
+    from datetime import timedelta
+    import torch.distributed as dist
+    path = os.path.join(out_dir, "store_port")
+    if rank == 0:
+        store = dist.TCPStore("127.0.0.1", 0, world, is_master=True, timeout=timedelta(seconds=120), wait_for_workers=False)
+        with open(path + ".tmp", "w") as f:
+            f.write(str(store.port))
+        os.replace(path + ".tmp", path)
+    else:
+        t_end = time.time() + 120
+        while not os.path.exists(path):
+            if time.time() > t_end:
+                raise TimeoutError("rank 0 never published its store port")
+            time.sleep(0.005)
+        store = dist.TCPStore("127.0.0.1", int(open(path).read()), world, is_master=False, timeout=timedelta(seconds=120))
+    dist.init_process_group("gloo", store=store, rank=rank, world_size=world)
+    return dist
 
 
 def _entries_from_indices(idx, i0):
@@ -37,11 +57,8 @@ def _indices_from_entries(ent):
     return np.array(out, dtype=np.uint32)
 
 
-def _worker(rank, world, port, grid, out_dir):
-    import torch.distributed as dist
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _worker(rank, world, grid, out_dir):
+    dist = _init_gloo(rank, world, out_dir)
     try:
         from oracle import carve_c
         from voxcarve import slabs
@@ -51,7 +68,8 @@ def _worker(rank, world, port, grid, out_dir):
         res = carve_c.carve(*grid, fx.oracle_cams(cams), masks, frames, index_range=(i0, i1), threads=1)
         b = res["bgr"].astype(np.uint64)
         rec = res["idx"].astype(np.uint64) | (b[:, 2] << 32) | (b[:, 1] << 40) | (b[:, 0] << 48) | (1 << 56)
-        tr = slabs.TorchTransport()
+        from torch_transport import TorchTransport
+        tr = TorchTransport()
         counts, total = tr.allgather_records(rec)
         assert int(counts[rank]) == rec.size
         np.save(os.path.join(out_dir, "gathered_%d.npy" % rank), tr.fetch())
@@ -68,8 +86,7 @@ def test_slab_split_allgather_equals_single_rank(built, tmp_path, world, grid):
     import torch.multiprocessing as mp
     from oracle import carve_c
     from voxcarve.engine import unpack_records
-    port = _free_port()
-    mp.spawn(_worker, args=(world, port, grid, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, grid, str(tmp_path)), nprocs=world, join=True)
     cams, masks = fx.golden_cameras(), fx.golden_masks()
     frames = fx.synthetic_frames(4, *masks[0].shape)
     full = carve_c.carve(*grid, fx.oracle_cams(cams), masks, frames)
@@ -110,7 +127,7 @@ def test_shm_fallback_transport(tmp_path):
     """The /dev/shm exchange bench.py falls back to when no RCCL communicator can be made."""
     import torch.multiprocessing as mp
     world = 3
-    mp.spawn(_shm_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_shm_worker, args=(world, _launch_key(), str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / ("ok_%d.npy" % r)).exists() for r in range(world))
 
 
@@ -132,7 +149,7 @@ def test_rendezvous_decision_is_collective(tmp_path, fail_rank):
     import multiprocessing as mp
     import struct
     from voxcarve import slabs
-    port = _free_port()
+    port = _launch_key()
     os.environ["MASTER_PORT"] = str(port)
     d = slabs._launch_dir(os.getpid())           # the workers are children of THIS process: that is their launch key
     os.makedirs(d, exist_ok=True)

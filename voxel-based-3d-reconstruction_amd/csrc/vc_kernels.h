@@ -1028,10 +1028,14 @@ __global__ __launch_bounds__(kBlock) void k_build_lut(const CarveParams p, int32
 // A table handed in from outside (vc_upload_lut: y-major int32 [C][n_pad], what vc_fetch_lut gives out) is adopted into the
 // layout the kernels read.  TILE: element e of tile word T is row r = e / 16 of its row quad, y = 16 * ty + e % 16 -- the table
 // is permuted into tile order and the tile words' pixel boxes are reduced from it; else only the y-line words' boxes are.
+// A foreign table cannot point outside the masks, and -1 is the only negative value the kernels know ("outside the image"; the
+// per-voxel level keeps -2 for itself): anything outside [-1, H*W) is stored as -1 -- into lut_tile (TILE), or back over the
+// entry itself (y-major: `lut` and `lut_out` are the same buffer, every thread rewrites only what it read).
 template <bool TILE>
-__global__ __launch_bounds__(kBlock) void k_adopt_lut(const CarveParams p, const int32_t *__restrict__ lut,
-                                                      int32_t *__restrict__ lut_tile, uint64_t *__restrict__ box)
+__global__ __launch_bounds__(kBlock) void k_adopt_lut(const CarveParams p, const int32_t *lut,
+                                                      int32_t *lut_out, uint64_t *__restrict__ box)
 {
+    int32_t *lut_tile = lut_out;
     const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;      // grid covers n_pad exactly
     const uint64_t T = t >> 6;
     const uint32_t e = (uint32_t)t & 63u, r = e >> 4, yy = e & 15u;
@@ -1046,8 +1050,10 @@ __global__ __launch_bounds__(kBlock) void k_adopt_lut(const CarveParams p, const
     const uint64_t nwords = p.n_pad >> 6;
     for (uint32_t c = 0; c < p.C; ++c) {
         int32_t off = valid ? lut[(size_t)c * p.n_pad + j] : -1;
-        if (off >= (int32_t)(p.H * p.W)) off = -1;                        // a foreign table cannot point outside the masks
+        const int32_t raw = off;
+        if (off >= (int32_t)(p.H * p.W) || off < -1) off = -1;
         if (TILE) lut_tile[(size_t)c * p.n_pad + t] = off;
+        else if (valid && off != raw) lut_out[(size_t)c * p.n_pad + j] = off;
         const uint32_t pv = off >= 0 ? (uint32_t)off / p.W : 0u;
         const uint32_t pu = off >= 0 ? (uint32_t)off - pv * p.W : 0u;
         const uint32_t u0 = wave_min_u32(off >= 0 ? pu : 0xffffu), u1 = wave_max_u32(pu);

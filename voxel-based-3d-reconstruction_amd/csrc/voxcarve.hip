@@ -118,6 +118,7 @@ struct Slot {
     // and behind the last record expansion that read its bits / images on the second stream.  The next preparation waits for both.
     hipEvent_t e_carve = nullptr, e_emit = nullptr;
     bool up_pending = false, carve_pending = false, emit_pending = false;
+    uint32_t gen = 0;           // preparations so far: a step remembers the one it ran on (vc_carve_end's regrow path)
 };
 
 // np.linspace(lo, hi, num=n) in float64: y[k] = k*step + lo (two roundings), y[n-1] = hi
@@ -167,7 +168,7 @@ struct StepBuf {
     uint64_t *h_counts = nullptr;            // pinned, 2 per rank
     bool counts_exchanged = false;           // vc_carve_begin already packed and all-gathered the counts
     int mode = 0, color_cam = -1;            // what the step was run with (vc_expand_entries colours the same way)
-    uint32_t slot = 0;
+    uint32_t slot = 0, slot_gen = 0;         // frame set the step read, and which preparation of it
     uint64_t n = 0, survivors = 0;
 };
 
@@ -184,6 +185,13 @@ struct vc_ctx {
     hipEvent_t ev_h[2] = {nullptr, nullptr};   // around the last mask upload (h2d_ms)
     bool h2d_pending = false;
     int overlap = 1;                 // (one stream when a communicator is attached: its collectives order everything)
+    // How the streams share the chip.  The record expansion fills every wave slot (65 536 waves of streaming work); the carve
+    // chain is a row of short, latency-bound launches that then queue for slots behind it.  stream_priority: carve + preparation
+    // streams at the highest queue priority, the expansion stream at the lowest -- the dispatcher hands a freed slot to the
+    // carve chain first.  reserve_cus: k compute units per XCD (k x 8 of 256) are left out of the expansion stream's CU mask
+    // (hipExtStreamCreateWithCUMask; no priority then: that call has none), so the carve chain always finds free slots there.
+    int stream_priority = 1;
+    int reserve_cus = 0;
     StepBuf sb[kDepth];
     int head = 0, npending = 0, cur = -1;    // next set to issue into, steps in flight, set holding the fetched result
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -311,6 +319,45 @@ struct vc_ctx {
 };
 
 namespace {
+
+int fail(vc_ctx *ctx, int code, const char *fmt, ...);
+
+// (Re)creates the three streams for ctx->stream_priority / ctx->reserve_cus.  Nothing may be in flight.
+hipError_t make_streams(vc_ctx *ctx)
+{
+    hipStream_t *all[3] = {&ctx->stream, &ctx->stream2, &ctx->stream_up};
+    for (hipStream_t *st : all) {
+        if (!*st) continue;
+        hipError_t e = hipStreamSynchronize(*st);
+        if (e == hipSuccess) e = hipStreamDestroy(*st);
+        if (e != hipSuccess) return e;
+        *st = nullptr;
+    }
+    int least = 0, greatest = 0;                                 // numerically: greatest priority <= least priority
+    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (e != hipSuccess) return e;
+    const bool prio = ctx->stream_priority && least != greatest;
+    if (ctx->reserve_cus > 0) {
+        hipDeviceProp_t prop;
+        e = hipGetDeviceProperties(&prop, ctx->device);
+        if (e != hipSuccess) return e;
+        // the driver deals the mask's bits round-robin over the XCDs (bit i -> XCD i % 8): the first 8 k bits are k compute
+        // units of every XCD
+        const uint32_t ncu = (uint32_t)prop.multiProcessorCount, words = (ncu + 31) / 32;
+        const uint32_t reserved = (uint32_t)ctx->reserve_cus * 8u < ncu ? (uint32_t)ctx->reserve_cus * 8u : ncu / 2;
+        std::vector<uint32_t> rest(words, 0u);
+        for (uint32_t i = reserved; i < ncu; ++i) rest[i >> 5] |= 1u << (i & 31u);
+        e = hipExtStreamCreateWithCUMask(&ctx->stream2, words, rest.data());
+        if (e != hipSuccess) return e;
+    } else {
+        e = prio ? hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, least)
+                 : hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+    }
+    e = prio ? hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, greatest) : hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) return e;
+    return prio ? hipStreamCreateWithPriority(&ctx->stream_up, hipStreamNonBlocking, greatest) : hipStreamCreateWithFlags(&ctx->stream_up, hipStreamNonBlocking);
+}
 
 int fail(vc_ctx *ctx, int code, const char *fmt, ...)
 {
@@ -548,6 +595,7 @@ int ensure_prepared(vc_ctx *ctx, Slot &s, bool want_grids, const CarveParams *cp
     if (s.carve_pending) { VC_HIP(ctx, hipStreamWaitEvent(st, s.e_carve, 0)); s.carve_pending = false; }
     if (s.emit_pending) { VC_HIP(ctx, hipStreamWaitEvent(st, s.e_emit, 0)); s.emit_pending = false; }
     s.prep_timed = timed;
+    s.gen++;
     if (timed) VC_HIP(ctx, hipEventRecord(s.e_p0, st));
     if (!s.bits_valid) {
         VC_TRY(ensure(ctx, s.bits, (size_t)ctx->mwords * C));
@@ -921,9 +969,7 @@ int vc_create(int device, vc_ctx **out)
     vc_ctx *ctx = new vc_ctx();
     ctx->device = device;
     memset(&ctx->tm, 0, sizeof ctx->tm);
-    hipError_t e1 = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    if (e1 == hipSuccess) e1 = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
-    if (e1 == hipSuccess) e1 = hipStreamCreateWithFlags(&ctx->stream_up, hipStreamNonBlocking);
+    hipError_t e1 = make_streams(ctx);
     for (int k = 0; k < 2 && e1 == hipSuccess; ++k) e1 = hipEventCreate(&ctx->ev_h[k]);
     for (int k = 0; k < kDepth && e1 == hipSuccess; ++k) {
         StepBuf &b = ctx->sb[k];
@@ -974,7 +1020,7 @@ int vc_destroy(vc_ctx *ctx)
     release(ctx->d_mcgtoff); release(ctx->d_mcfaces); release(ctx->d_mcbv); release(ctx->d_mcbvoff); release(ctx->d_mcbt); release(ctx->d_mcbtoff);
     release(ctx->d_mcverts);
     for (StepBuf &b : ctx->sb) {
-        release(b.words); release(b.groupcnt); release(b.groupoff); release(b.blocksum); release(b.blockoff); release(b.records);
+        release(b.words); release(b.groupcnt); release(b.groupoff); release(b.groupnz); release(b.blocksum); release(b.blockoff); release(b.records);
         release(b.ent); release(b.mine); release(b.counts);
         release(b.busyoff); release(b.busysum); release(b.busyblock); release(b.busylist);
         if (b.h_counts) (void)hipHostFree(b.h_counts);
@@ -1205,7 +1251,7 @@ static int ensure_ymajor(vc_ctx *ctx)
         if (ctx->lut_foreign && ctx->tile_valid) {               // a table that was handed in: permuted back, never re-projected
             hipLaunchKernelGGL(k_untile_lut, dim3(grid_for(n_pad)), dim3(kBlock), 0, ctx->stream, p, (const int32_t *)ctx->d_lut_tile.ptr, ctx->d_lut.ptr);
             hipLaunchKernelGGL(k_adopt_lut<false>, dim3(grid_for(n_pad)), dim3(kBlock), 0, ctx->stream, p, (const int32_t *)ctx->d_lut.ptr,
-                               (int32_t *)nullptr, ctx->d_bbox.ptr);
+                               ctx->d_lut.ptr, ctx->d_bbox.ptr);
         }
         else hipLaunchKernelGGL(k_build_lut<false>, dim3(grid_for(n_pad)), dim3(kBlock), 0, ctx->stream, p, ctx->d_lut.ptr, ctx->d_bbox.ptr);
         VC_HIP(ctx, hipGetLastError());
@@ -1291,8 +1337,9 @@ int vc_upload_lut(vc_ctx *ctx, uint32_t cam, const int32_t *lut)
     } else {
         VC_TRY(ensure(ctx, ctx->d_bbox, (size_t)(n_pad / 64) * ctx->C));
         if (n) {
+            // (y-major path: the table stays where it is, so entries outside [-1, H*W) are rewritten to -1 IN PLACE)
             hipLaunchKernelGGL(k_adopt_lut<false>, dim3(grid_for(n_pad)), dim3(kBlock), 0, ctx->stream, p, (const int32_t *)ctx->d_lut.ptr,
-                               (int32_t *)nullptr, ctx->d_bbox.ptr);
+                               ctx->d_lut.ptr, ctx->d_bbox.ptr);
             VC_HIP(ctx, hipGetLastError());
         }
         VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1419,6 +1466,7 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
         p.groupnz = sb.groupnz.ptr;
         sb.nz_valid = true;
     }
+    sb.slot_gen = s.gen;
     if (s.prep_pending) { VC_HIP(ctx, hipStreamWaitEvent(ctx->stream, s.e_prep, 0)); s.prep_pending = false; }
     p.maskbits = s.bits.ptr;
     p.blockgrid = s.grid.ptr;
@@ -1608,11 +1656,12 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     e.capacity = sb.records.cap;
     e.busylist = sb.busylist.ptr; e.busycount = sb.busyblock.ptr;
     sb.emit_timed = false;
+    bool scan_recorded = false;                                  // e_scan recorded by THIS step (Slot::carve_pending may still be set by an earlier one)
     if (!sb.no_records && (s3 != ctx->stream || sb.carve_timed)) {
         VC_HIP(ctx, hipEventRecord(sb.e_scan, ctx->stream));     // cross-stream dependency; with e2 it also brackets the expansion
         if (s3 != ctx->stream) VC_HIP(ctx, hipStreamWaitEvent(s3, sb.e_scan, 0));
         sb.emit_timed = true;
-        s.e_carve = sb.e_scan; s.carve_pending = true;           // the slot's next preparation waits for the kernels that read its bits / grids
+        scan_recorded = true;
     }
     if (!sb.no_records) {
         VC_TRY(launch_emit(ctx, sb, s3));
@@ -1624,7 +1673,11 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     }
     VC_HIP(ctx, hipEventRecord(sb.e2, sb.no_records ? s2 : s3));
     if (!sb.no_records && s3 != ctx->stream) { s.e_emit = sb.e2; s.emit_pending = true; }   // the expansion reads the slot's bits / images
-    if (!s.carve_pending) { s.e_carve = sb.e2; s.carve_pending = true; }                       // (no e_scan recorded: e2 is behind the carve kernels too)
+    // the slot's next preparation waits for the kernels of THIS step that read its bits / grids: always this step's own event
+    // (a flag left set by an earlier step on the same slot must not keep that step's event in place: the preparation would
+    // then overwrite bits and grids under this step's carve).  Without e_scan, e2 is behind the carve kernels too.
+    s.e_carve = scan_recorded ? sb.e_scan : sb.e2;
+    s.carve_pending = true;
     sb.pending = true;
     sb.used = true;
     ctx->head = (ctx->head + 1) % kDepth;
@@ -1647,6 +1700,14 @@ int vc_carve_end(vc_ctx *ctx, uint64_t *n_out)
         VC_HIP(ctx, hipEventSynchronize(sb.e2));
         uint64_t total = *sb.h_total;
         if (!sb.no_records && total > sb.records.cap) {                    // regrow once, expand again
+            // the second expansion reads the step's frame set (bits, image) NOW: if a later vc_carve_begin has prepared the slot
+            // again in the meantime, colours and seen flags would come from the newer frame -- refuse instead of mixing
+            if (sb.color_cam >= 0 && ctx->slots[sb.slot].gen != sb.slot_gen) {
+                sb.pending = false; ctx->npending--;
+                return fail(ctx, VC_ERR_ARG, "step overflowed its record buffer (%llu > %llu) and frame set %u has been prepared again "
+                            "since: its records cannot be re-expanded; collect a step before re-using its slot with new input",
+                            (unsigned long long)total, (unsigned long long)sb.records.cap, sb.slot);
+            }
             VC_TRY(ensure(ctx, sb.records, (size_t)(total + total / 8 + 1024)));
             sb.emit.records = sb.records.ptr;
             sb.emit.capacity = sb.records.cap;
@@ -1872,6 +1933,13 @@ int vc_set_option(vc_ctx *ctx, const char *name, int value)
     else if (k == "emit_lanes") ctx->emit_lanes = value != 0;
     else if (k == "overlap") ctx->overlap = value != 0;
     else if (k == "timing_detail") ctx->timing_detail = value != 0;
+    else if ((k == "stream_priority" && (value == 0 || value == 1)) || (k == "reserve_cus" && value >= 0 && value <= 16)) {
+        if (ctx->npending) return fail(ctx, VC_ERR_ARG, "carve steps are in flight: collect them with vc_carve_end first");
+        VC_HIP(ctx, hipSetDevice(ctx->device));
+        VC_TRY(vc_synchronize(ctx));
+        (k == "stream_priority" ? ctx->stream_priority : ctx->reserve_cus) = value;
+        VC_HIP(ctx, make_streams(ctx));
+    }
     else if (k == "cull") ctx->cull = value != 0;
     else if (k == "bricks") ctx->bricks = value != 0;
     else if (k == "dbg") ctx->dbg = value;

@@ -178,6 +178,10 @@ class CarveEngine:
             lut = z["lut"]
             if lut.dtype != np.int32 or lut.shape != (self.n_cameras, self.n_voxels):
                 raise _lib.VoxcarveError("lookup table %s: array %s %s, expected int32 %s" % (path, lut.dtype, lut.shape, (self.n_cameras, self.n_voxels)))
+            hw = int(self.image_size[0]) * int(self.image_size[1])            # (equal to the file's: checked above)
+            lo, hi = (int(lut.min()), int(lut.max())) if lut.size else (-1, -1)
+            if lo < -1 or hi >= hw:
+                raise _lib.VoxcarveError("lookup table %s holds entries outside [-1, H*W) (min %d, max %d): stale or corrupt file" % (path, lo, hi))
             self.upload_lut(lut)
 
     def upload_lut(self, lut):

@@ -146,23 +146,18 @@ def plot_marching_cubes(voxels_status, rotate=True, plot_output_path="plots", pl
     if rotate:
         voxels_status = np.rot90(voxels_status, 2)                   # reference :138-139
     verts, faces = marching_cubes(voxels_status, 0)
-    import matplotlib
-    matplotlib.use("Agg")
-    import matplotlib.pyplot as plt
+    # drawn on a Figure of its own with the Agg canvas: the caller's global matplotlib backend is left alone
+    from matplotlib.backends.backend_agg import FigureCanvasAgg
+    from matplotlib.figure import Figure
     from mpl_toolkits.mplot3d.art3d import Poly3DCollection
-    fig = plt.figure(figsize=(10, 10))
+    fig = Figure(figsize=(10, 10))
+    FigureCanvasAgg(fig)
     ax = fig.add_subplot(111, projection="3d")
-    mesh = Poly3DCollection(verts[faces.astype(np.int64)])
-    mesh.set_edgecolor("k")
-    ax.add_collection3d(mesh)
-    ax.set_xlabel("X")
-    ax.set_ylabel("Y")
-    ax.set_zlabel("z-axis")
-    ax.set_xlim(0, voxels_status.shape[2])
-    ax.set_ylim(0, voxels_status.shape[1])
-    ax.set_zlim(0, voxels_status.shape[0])
-    plt.tight_layout()
+    surface = Poly3DCollection(verts[faces.astype(np.int64)], edgecolor="k")
+    ax.add_collection3d(surface)
+    d0, d1, d2 = voxels_status.shape
+    ax.set(xlabel="X", ylabel="Y", zlabel="z-axis", xlim=(0, d2), ylim=(0, d1), zlim=(0, d0))
+    fig.tight_layout()
     os.makedirs(plot_output_path, exist_ok=True)
-    plt.savefig(os.path.join(plot_output_path, plot_output_filename))
-    plt.close(fig)
+    fig.savefig(os.path.join(plot_output_path, plot_output_filename))
     return verts, faces
