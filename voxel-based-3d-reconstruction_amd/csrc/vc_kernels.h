@@ -140,7 +140,10 @@ struct CarveParams {
     uint32_t C, H, W, mwords;
     uint32_t min_views;
     uint32_t dbg;               // experiments only (vc_set_option("dbg", ...), scripts/exp_bricks.py): 1 = skip the voxel level (undecided words
-                                // count as alive), 2 = skip the word level too; results are then WRONG on purpose
+                                // count as alive), 2 = skip the word level too; 8 = preparation, carve and scan kernels launch and return
+                                // at once (32 / 64 / 128 / 256 / 512: only the preparation / cull + word level / voxel level /
+                                // assembly / scans do), 16 = the record expansion does (scripts/exp_streams.py: what do the launches cost each
+                                // other, apart from their work); results are then WRONG on purpose
     CamDev cam[kMaxCameras];
 };
 
@@ -166,6 +169,7 @@ struct EmitParams {
     uint32_t nx, ny, z0;
     uint32_t H, W;
     int has_cam;
+    uint32_t dbg;               // experiments only (see CarveParams::dbg): 16 = the expansion launches and returns
     CamDev cam;
 };
 
@@ -1191,6 +1195,7 @@ __device__ __forceinline__ void shard_locate(const ShardView &v, uint32_t t, uin
 
 __global__ __launch_bounds__(kWideBlock) void k_cull_bricks(const CarveParams p, const BrickLists bl, uint32_t ngroups)
 {
+    if (p.dbg & 72u) return;                                       // experiment: launch only (scripts/exp_streams.py)
     extern __shared__ uint32_t s_grid[];
     stage_grids(s_grid, p.coarsegrid ? p.coarsegrid : p.blockgrid);
     __shared__ uint32_t s_order[kMaxCameras];
@@ -1283,6 +1288,7 @@ __global__ __launch_bounds__(kBlock) void k_brick_boxes_bm(const CarveParams p, 
 
 __global__ __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_brick_words(const CarveParams p, const BrickLists bl)
 {
+    if (p.dbg & 72u) return;
     extern __shared__ uint32_t s_grid[];
     uint32_t *cnt = bl.counters + bl.parity * 3 * kShards * kShardStride;
     const ShardView sv = shard_view(cnt, 1, threadIdx.x & 63u);
@@ -1341,6 +1347,7 @@ __global__ __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu(8, 8
 template <bool LUT, bool PAIR = true>
 __global__ __launch_bounds__(kBlock) void k_voxel_words(const CarveParams p, const BrickLists bl)
 {
+    if (p.dbg & 136u) return;
     constexpr int B = 8;
     const uint32_t lane = threadIdx.x & 63u;
     const ShardView sv = shard_view(bl.counters + (bl.parity * 3 + 2) * kShards * kShardStride, B, lane);    // in batches of B words, per shard
@@ -1432,6 +1439,7 @@ __global__ __launch_bounds__(kBlock) void k_voxel_words(const CarveParams p, con
 // side by side along x in that layer.  Their loads are issued together; the column's live / full bits are read once.
 __global__ __launch_bounds__(kBlock) void k_assemble(const CarveParams p, const BrickLists bl)
 {
+    if (p.dbg & 264u) return;
     const uint32_t lane = threadIdx.x & 63u;
     const ShardView sv = shard_view(bl.counters + (bl.parity * 3 + 1) * kShards * kShardStride, 1, lane);
     const uint32_t ncols = sv.total;
@@ -1552,10 +1560,12 @@ struct PrepParams {
     uint32_t C, H, W, HW, mwords, nframes;
     uint32_t parity;                   // which of the two box sets this frame fills
     uint32_t iters;                    // 256-word chunks per packing workgroup (large frame sets: fewer workgroups meet on the boxes)
+    uint32_t dbg;                      // experiments only (see CarveParams::dbg)
 };
 
 __global__ __launch_bounds__(kBlock) void k_prep_pack(const PrepParams p)
 {
+    if (p.dbg & 40u) return;
     __shared__ uint32_t s_red[kBlock / 64][4];
     // workgroups [0, C * pw): camera y packs iters x 256 mask words each; then fw per image: 1024 pixels each
     const uint32_t pw = (p.mwords + kBlock * p.iters - 1) / (kBlock * p.iters), fw = (p.HW + 4 * kBlock - 1) / (4 * kBlock);
@@ -1668,6 +1678,7 @@ constexpr uint32_t kEstPerThread = 4;
 __global__ __launch_bounds__(kBlock) void k_prep_grid(const CarveParams p, uint32_t *grid, uint32_t *boxes_rw, uint32_t parity,
                                                       uint32_t min_shift, uint32_t budget_words, uint32_t nsamples, uint32_t grid_wgs)
 {
+    if (p.dbg & 40u) return;
     const uint32_t *boxes = boxes_rw;
     uint32_t *counts = boxes_rw + kCountBase;
     __shared__ uint32_t s_hits[kMaxCameras];
@@ -1976,32 +1987,61 @@ __global__ __launch_bounds__(kBlock) void k_count_entries(const uint64_t *__rest
 // Level 1: exclusive scan of the group counts inside blocks of kScanBlock groups.
 // A single-block launch (<= 1024 groups: grids up to 4 M voxels) also finishes level 2 itself.
 // The grand total goes to device memory AND straight to a page-locked host word (no copy kernel).
-__global__ __launch_bounds__(kScanBlock) void k_scan_groups(const uint32_t *__restrict__ cnt, uint32_t ngroups,
-                                                            uint32_t *__restrict__ off, uint64_t *__restrict__ blocksum,
-                                                            uint64_t *__restrict__ blockoff, uint64_t *__restrict__ total_host,
-                                                            uint32_t *__restrict__ busyoff, uint32_t *__restrict__ busysum,
-                                                            uint32_t *__restrict__ busyblock)
+// Workgroups of 256 threads, four consecutive groups each: a 1024-thread workgroup needs sixteen free wave slots on ONE compute
+// unit, and while another stream's kernel keeps refilling every slot that frees up (the record expansion's 16 384 four-wave
+// workgroups) it finds them only once that kernel has nothing left to dispatch -- scripts/exp_streams.py: the two scan launches,
+// 11 us of work, cost the pipelined step 68 us.
+constexpr uint32_t kScanThreads = 256, kScanPer = kScanBlock / kScanThreads;
+__global__ __launch_bounds__(kScanThreads) void k_scan_groups(const uint32_t *__restrict__ cnt, uint32_t ngroups,
+                                                              uint32_t *__restrict__ off, uint64_t *__restrict__ blocksum,
+                                                              uint64_t *__restrict__ blockoff, uint64_t *__restrict__ total_host,
+                                                              uint32_t *__restrict__ busyoff, uint32_t *__restrict__ busysum,
+                                                              uint32_t *__restrict__ busyblock, uint32_t dbg = 0)
 {
-    __shared__ uint32_t wsum[kScanBlock / 64], wbusy[kScanBlock / 64];
+    if (dbg & (8u | 512u)) return;
+    __shared__ uint32_t wsum[kScanThreads / 64], wbusy[kScanThreads / 64];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    const uint32_t i = blockIdx.x * kScanBlock + t;
-    const uint32_t c = (i < ngroups) ? cnt[i] : 0u;      // <= 4096 each: a block total fits u32
-    const uint32_t incl = wave_inclusive_scan(c, lane);
+    const uint32_t i0 = blockIdx.x * kScanBlock + kScanPer * t;
+    uint32_t c[kScanPer];                                // <= 4096 each: a block total fits u32
+    if (i0 + kScanPer <= ngroups) {                      // (16-byte aligned: i0 is a multiple of four)
+        const uint4 v = *reinterpret_cast<const uint4 *>(cnt + i0);
+        c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
+    } else {
+#pragma unroll
+        for (uint32_t k = 0; k < kScanPer; ++k) c[k] = (i0 + k < ngroups) ? cnt[i0 + k] : 0u;
+    }
+    static_assert(kScanPer == 4, "four groups per thread");
+    const uint32_t own = c[0] + c[1] + c[2] + c[3];
+    const uint32_t incl = wave_inclusive_scan(own, lane);
     // busyoff != null: the same scan over "group has survivors", for the list of busy groups (k_finish_scan)
-    const uint32_t f = (busyoff && c) ? 1u : 0u;
-    const uint32_t fincl = busyoff ? wave_inclusive_scan(f, lane) : 0u;
+    uint32_t f[kScanPer], fown = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kScanPer; ++k) { f[k] = (busyoff && c[k]) ? 1u : 0u; fown += f[k]; }
+    const uint32_t fincl = busyoff ? wave_inclusive_scan(fown, lane) : 0u;
     if (lane == 63) { wsum[wave] = incl; wbusy[wave] = fincl; }
     __syncthreads();
     uint32_t before = 0, total = 0, fbefore = 0, ftotal = 0;
 #pragma unroll
-    for (uint32_t k = 0; k < kScanBlock / 64; ++k) {
+    for (uint32_t k = 0; k < kScanThreads / 64; ++k) {
         const uint32_t s = wsum[k], fs = wbusy[k];
         if (k < wave) { before += s; fbefore += fs; }
         total += s; ftotal += fs;
     }
-    if (i < ngroups) {
-        off[i] = before + incl - c;
-        if (busyoff) busyoff[i] = fbefore + fincl - f;
+    uint32_t run = before + incl - own, frun = fbefore + fincl - fown;
+    uint32_t o[kScanPer], fo[kScanPer];
+#pragma unroll
+    for (uint32_t k = 0; k < kScanPer; ++k) { o[k] = run; run += c[k]; fo[k] = frun; frun += f[k]; }
+    if (i0 + kScanPer <= ngroups) {
+        *reinterpret_cast<uint4 *>(off + i0) = make_uint4(o[0], o[1], o[2], o[3]);
+        if (busyoff) *reinterpret_cast<uint4 *>(busyoff + i0) = make_uint4(fo[0], fo[1], fo[2], fo[3]);
+    } else {
+#pragma unroll
+        for (uint32_t k = 0; k < kScanPer; ++k) {
+            if (i0 + k < ngroups) {
+                off[i0 + k] = o[k];
+                if (busyoff) busyoff[i0 + k] = fo[k];
+            }
+        }
     }
     if (t == 0) {
         blocksum[blockIdx.x] = total;
@@ -2015,14 +2055,16 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_groups(const uint32_t *__re
     }
 }
 
-// Level 2: exclusive scan of the (at most kScanBlock) block sums; blockoff[nblocks] = total.
-__global__ __launch_bounds__(kScanBlock) void k_scan_blocks(const uint64_t *__restrict__ blocksum, uint32_t nblocks,
-                                                            uint64_t *__restrict__ blockoff, uint64_t *__restrict__ total_host)
+// Level 2: exclusive scan of the (at most kScanBlock) block sums; blockoff[nblocks] = total.  Thread t owns blocks 4t .. 4t+3.
+__global__ __launch_bounds__(kScanThreads) void k_scan_blocks(const uint64_t *__restrict__ blocksum, uint32_t nblocks,
+                                                              uint64_t *__restrict__ blockoff, uint64_t *__restrict__ total_host)
 {
-    __shared__ uint64_t wsum[kScanBlock / 64];
+    __shared__ uint64_t wsum[kScanThreads / 64];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    const uint64_t c = (t < nblocks) ? blocksum[t] : 0ull;
-    uint64_t incl = c;
+    uint64_t v[kScanPer], own = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kScanPer; ++k) { v[k] = (kScanPer * t + k < nblocks) ? blocksum[kScanPer * t + k] : 0ull; own += v[k]; }
+    uint64_t incl = own;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const uint64_t o = __shfl_up(incl, d);
@@ -2030,14 +2072,17 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_blocks(const uint64_t *__re
     }
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    uint64_t before = 0, total = 0;
+    uint64_t base = incl - own, total = 0;
 #pragma unroll
-    for (uint32_t k = 0; k < kScanBlock / 64; ++k) {
-        const uint64_t s = wsum[k];
-        if (k < wave) before += s;
-        total += s;
+    for (uint32_t k = 0; k < kScanThreads / 64; ++k) {
+        if (k < wave) base += wsum[k];
+        total += wsum[k];
     }
-    if (t < nblocks) blockoff[t] = before + incl - c;
+#pragma unroll
+    for (uint32_t k = 0; k < kScanPer; ++k) {
+        if (kScanPer * t + k < nblocks) blockoff[kScanPer * t + k] = base;
+        base += v[k];
+    }
     if (t == 0) {
         blockoff[nblocks] = total;
         *total_host = total;
@@ -2052,8 +2097,9 @@ __global__ __launch_bounds__(kBlock) void k_finish_scan(const uint64_t *__restri
                                                         uint64_t *__restrict__ blockoff, uint64_t *__restrict__ total_host,
                                                         const uint32_t *__restrict__ busysum, uint32_t *__restrict__ busycount,
                                                         const uint32_t *__restrict__ cnt, uint32_t ngroups,
-                                                        const uint32_t *__restrict__ busyoff, uint32_t *__restrict__ list)
+                                                        const uint32_t *__restrict__ busyoff, uint32_t *__restrict__ list, uint32_t dbg = 0)
 {
+    if (dbg & (8u | 512u)) return;
     __shared__ uint32_t wred[kBlock / 64];
     __shared__ uint64_t wsum[kBlock / 64];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
@@ -2395,6 +2441,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_lanes(const EmitParams p)
 template <bool FROM_LUT, bool ALLSEEN, int EB>
 __global__ __launch_bounds__(kBlock) void k_emit_busy(const EmitParams p)
 {
+    if (p.dbg & 16u) return;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t w = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
     const uint32_t nwaves = gridDim.x * (kBlock / 64);

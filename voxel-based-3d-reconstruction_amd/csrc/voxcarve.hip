@@ -192,6 +192,7 @@ struct vc_ctx {
     // (hipExtStreamCreateWithCUMask; no priority then: that call has none), so the carve chain always finds free slots there.
     int stream_priority = 1;
     int reserve_cus = 0;
+    int event_scope = 1;             // 1: the events the streams exchange release to the DEVICE only (no system-scope write-back)
     StepBuf sb[kDepth];
     int head = 0, npending = 0, cur = -1;    // next set to issue into, steps in flight, set holding the fetched result
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -357,6 +358,34 @@ hipError_t make_streams(vc_ctx *ctx)
     e = prio ? hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, greatest) : hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) return e;
     return prio ? hipStreamCreateWithPriority(&ctx->stream_up, hipStreamNonBlocking, greatest) : hipStreamCreateWithFlags(&ctx->stream_up, hipStreamNonBlocking);
+}
+
+// The events that only order one stream behind another ({scan done} of a step: carve stream -> expansion stream; a frame set's
+// {prepared}: upload stream -> carve stream) are recorded between two kernels of the critical path.  By default an event
+// performs a SYSTEM-scope release when it is recorded (the host may want to look at what came before it): on this chip that is
+// a write-back of every XCD's L2 -- with the expansion's 238 MB of records in flight beside it, ~12 us during which the recording
+// stream stands still.  Nobody on the host ever looks at anything through these events: hipEventReleaseToDevice.  event_scope 2
+// does the same to a step's {done} event, which the host DOES wait for (the survivor count it then reads sits in page-locked
+// host memory, written past the caches).
+hipError_t make_events(vc_ctx *ctx)
+{
+    for (uint32_t r = 0; r < kStepRing; ++r) {
+        for (int i = 0; i < 2; ++i) {
+            if (ctx->step_ev[r][i]) { hipError_t e = hipEventDestroy(ctx->step_ev[r][i]); if (e != hipSuccess) return e; ctx->step_ev[r][i] = nullptr; }
+            const bool dev = ctx->event_scope >= (i == 0 ? 1 : 2);
+            hipError_t e = hipEventCreateWithFlags(&ctx->step_ev[r][i], dev ? hipEventReleaseToDevice : hipEventDefault);
+            if (e != hipSuccess) return e;
+        }
+    }
+    for (Slot &s : ctx->slots) {
+        if (!s.e_prep) continue;
+        hipError_t e = hipEventDestroy(s.e_prep);
+        if (e != hipSuccess) return e;
+        e = hipEventCreateWithFlags(&s.e_prep, ctx->event_scope >= 1 ? hipEventReleaseToDevice : hipEventDefault);
+        if (e != hipSuccess) return e;
+        s.prep_pending = s.carve_pending = s.emit_pending = false;   // (everything has drained: nothing to wait for)
+    }
+    return hipSuccess;
 }
 
 int fail(vc_ctx *ctx, int code, const char *fmt, ...)
@@ -557,7 +586,7 @@ int slot_at(vc_ctx *ctx, uint32_t slot, Slot **out)
     if (s.have_frame.size() != ctx->C) { s.have_frame.assign(ctx->C, 0); s.frame_dirty.assign(ctx->C, 0); }
     if (!s.e_up) {
         VC_HIP(ctx, hipEventCreateWithFlags(&s.e_up, hipEventDisableTiming));
-        VC_HIP(ctx, hipEventCreate(&s.e_prep));
+        VC_HIP(ctx, hipEventCreateWithFlags(&s.e_prep, ctx->event_scope >= 1 ? hipEventReleaseToDevice : hipEventDefault));
         VC_HIP(ctx, hipEventCreate(&s.e_p0));
     }
     *out = &s;
@@ -667,6 +696,7 @@ int ensure_prepared(vc_ctx *ctx, Slot &s, bool want_grids, const CarveParams *cp
         pp.bits = s.bits.ptr; pp.grid = s.grid.ptr; pp.boxes = s.boxes.ptr;
         pp.C = C; pp.H = ctx->H; pp.W = ctx->W; pp.HW = (uint32_t)HW; pp.mwords = ctx->mwords;
         pp.parity = s.parity;
+        pp.dbg = (uint32_t)ctx->dbg;
         // about a thousand packing workgroups at most: every one of them looks at (and may update) its camera's box
         const uint64_t total_words = (uint64_t)ctx->mwords * C;
         pp.iters = (uint32_t)(total_words / (256ull * 1024ull));
@@ -743,11 +773,11 @@ int scan_counts(vc_ctx *ctx, hipStream_t st, const uint32_t *cnt, uint32_t ngrou
                 uint64_t *total_host)
 {
     const uint32_t nscan = (ngroups + kScanBlock - 1) / kScanBlock;
-    hipLaunchKernelGGL(k_scan_groups, dim3(nscan), dim3(kScanBlock), 0, st, cnt, ngroups, off, bsum, boff, total_host,
-                       (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
+    hipLaunchKernelGGL(k_scan_groups, dim3(nscan), dim3(kScanThreads), 0, st, cnt, ngroups, off, bsum, boff, total_host,
+                       (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u);
     VC_HIP(ctx, hipGetLastError());
     if (nscan > 1) {
-        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(kScanBlock), 0, st, bsum, nscan, boff, total_host);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(kScanThreads), 0, st, bsum, nscan, boff, total_host);
         VC_HIP(ctx, hipGetLastError());
     }
     return VC_OK;
@@ -982,8 +1012,7 @@ int vc_create(int device, vc_ctx **out)
     for (int i = 0; i < 4 && e1 == hipSuccess; ++i) e1 = hipEventCreate(&ctx->ev[i]);
     for (uint32_t r = 0; r < kGatherRing && e1 == hipSuccess; ++r)
         for (int i = 0; i < 3 && e1 == hipSuccess; ++i) e1 = hipEventCreate(&ctx->gx[r][i]);
-    for (uint32_t r = 0; r < kStepRing && e1 == hipSuccess; ++r)
-        for (int i = 0; i < 2 && e1 == hipSuccess; ++i) e1 = hipEventCreate(&ctx->step_ev[r][i]);
+    if (e1 == hipSuccess) e1 = make_events(ctx);
     if (e1 == hipSuccess) e1 = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_total), sizeof(uint64_t), hipHostMallocDefault);
     const char *fg = getenv("VOXCARVE_FORCE_GENERIC");
     ctx->force_generic = fg && fg[0] == '1';
@@ -1614,17 +1643,17 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
         VC_TRY(ensure(ctx, sb.busysum, kMaxScanBlocks));
         VC_TRY(ensure(ctx, sb.busyblock, 1));                    // the count of busy groups
     }
-    hipLaunchKernelGGL(k_scan_groups, dim3(nscan), dim3(kScanBlock), 0, s2, sb.groupcnt.ptr, ngroups, sb.groupoff.ptr,
+    hipLaunchKernelGGL(k_scan_groups, dim3(nscan), dim3(kScanThreads), 0, s2, sb.groupcnt.ptr, ngroups, sb.groupoff.ptr,
                        sb.blocksum.ptr, sb.blockoff.ptr, sb.h_total, sb.busy ? sb.busyoff.ptr : nullptr, sb.busysum.ptr,
-                       sb.busyblock.ptr);
+                       sb.busyblock.ptr, (uint32_t)ctx->dbg);
     VC_HIP(ctx, hipGetLastError());
     if (sb.busy) {
         // level 2 of both scans + the list in one launch (k_scan_groups has left the count in busyblock[0] when nscan == 1)
         hipLaunchKernelGGL(k_finish_scan, dim3(grid_for(ngroups)), block, 0, s2, sb.blocksum.ptr, nscan, sb.blockoff.ptr, sb.h_total,
-                           sb.busysum.ptr, sb.busyblock.ptr, sb.groupcnt.ptr, ngroups, sb.busyoff.ptr, sb.busylist.ptr);
+                           sb.busysum.ptr, sb.busyblock.ptr, sb.groupcnt.ptr, ngroups, sb.busyoff.ptr, sb.busylist.ptr, (uint32_t)ctx->dbg);
         VC_HIP(ctx, hipGetLastError());
     } else if (nscan > 1) {
-        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(kScanBlock), 0, s2, sb.blocksum.ptr, nscan, sb.blockoff.ptr, sb.h_total);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(kScanThreads), 0, s2, sb.blocksum.ptr, nscan, sb.blockoff.ptr, sb.h_total);
         VC_HIP(ctx, hipGetLastError());
     }
 
@@ -1655,6 +1684,7 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     e.records = sb.records.ptr;
     e.capacity = sb.records.cap;
     e.busylist = sb.busylist.ptr; e.busycount = sb.busyblock.ptr;
+    e.dbg = (uint32_t)ctx->dbg;
     sb.emit_timed = false;
     bool scan_recorded = false;                                  // e_scan recorded by THIS step (Slot::carve_pending may still be set by an earlier one)
     if (!sb.no_records && (s3 != ctx->stream || sb.carve_timed)) {
@@ -1933,6 +1963,13 @@ int vc_set_option(vc_ctx *ctx, const char *name, int value)
     else if (k == "emit_lanes") ctx->emit_lanes = value != 0;
     else if (k == "overlap") ctx->overlap = value != 0;
     else if (k == "timing_detail") ctx->timing_detail = value != 0;
+    else if (k == "event_scope" && value >= 0 && value <= 2) {
+        if (ctx->npending) return fail(ctx, VC_ERR_ARG, "carve steps are in flight: collect them with vc_carve_end first");
+        VC_HIP(ctx, hipSetDevice(ctx->device));
+        VC_TRY(vc_synchronize(ctx));
+        ctx->event_scope = value;
+        VC_HIP(ctx, make_events(ctx));
+    }
     else if ((k == "stream_priority" && (value == 0 || value == 1)) || (k == "reserve_cus" && value >= 0 && value <= 16)) {
         if (ctx->npending) return fail(ctx, VC_ERR_ARG, "carve steps are in flight: collect them with vc_carve_end first");
         VC_HIP(ctx, hipSetDevice(ctx->device));
