@@ -18,6 +18,7 @@
 //
 // There is no CPU path in this library: without a GPU vc_create fails (VC_ERR_NODEV).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <dlfcn.h>
 #include <rccl/rccl.h>   // types and enums only; the functions are resolved with dlsym
 
@@ -152,7 +153,8 @@ struct StepBuf {
     DevBuf<uint64_t> records;
     uint64_t *h_total = nullptr;             // pinned
     hipEvent_t e0 = nullptr, e_first = nullptr, e1 = nullptr, e_prep = nullptr;
-    hipEvent_t e2 = nullptr, e_scan = nullptr;   // borrowed from vc_ctx::step_ev for the step in this set (see there)
+    hipEvent_t e2 = nullptr, e_scan = nullptr, e_emit0 = nullptr;   // borrowed from vc_ctx::step_ev for the step in this set (see there)
+    bool emit_ridden = false;                // e_emit0 / e2 are the expansion launch's own begin and end
     bool prepped = false, prep_timed = false; // this step queued preparation kernels in front of its carve (timed: e_prep .. e0)
     bool carve_timed = false;                // e0 / e1 were recorded around the carve kernels (synchronous calls, timing_detail)
     bool emit_timed = false;                 // e_scan / e2 bracket the record expansion
@@ -192,6 +194,8 @@ struct vc_ctx {
     // (hipExtStreamCreateWithCUMask; no priority then: that call has none), so the carve chain always finds free slots there.
     int stream_priority = 1;
     int reserve_cus = 0;
+    int launch_events = 1;           // the events the streams exchange ride on the launch that precedes them (hipExtLaunchKernelGGL's stop event: the
+                                     // kernel's own completion signal) instead of a barrier packet of their own behind it (~3.5 us of stream time each)
     int event_scope = 1;             // 1: the events the streams exchange release to the DEVICE only (no system-scope write-back)
     StepBuf sb[kDepth];
     int head = 0, npending = 0, cur = -1;    // next set to issue into, steps in flight, set holding the fetched result
@@ -202,7 +206,7 @@ struct vc_ctx {
     hipEvent_t gx[kGatherRing][3] = {};
     // the same for a step's {scan done, step done}: frame sets remember them (Slot::e_carve, e_emit) for their next preparation,
     // kStepRing steps of distance keep that wait on the step that read the frame set and not on a newer one
-    hipEvent_t step_ev[kStepRing][2] = {};
+    hipEvent_t step_ev[kStepRing][3] = {};      // {scan done, step done, expansion begun}
     uint32_t step_next = 0;
     uint32_t gx_next = 0;
     std::string err;
@@ -370,9 +374,9 @@ hipError_t make_streams(vc_ctx *ctx)
 hipError_t make_events(vc_ctx *ctx)
 {
     for (uint32_t r = 0; r < kStepRing; ++r) {
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 3; ++i) {
             if (ctx->step_ev[r][i]) { hipError_t e = hipEventDestroy(ctx->step_ev[r][i]); if (e != hipSuccess) return e; ctx->step_ev[r][i] = nullptr; }
-            const bool dev = ctx->event_scope >= (i == 0 ? 1 : 2);
+            const bool dev = ctx->event_scope >= (i == 1 ? 2 : 1);
             hipError_t e = hipEventCreateWithFlags(&ctx->step_ev[r][i], dev ? hipEventReleaseToDevice : hipEventDefault);
             if (e != hipSuccess) return e;
         }
@@ -740,29 +744,30 @@ uint32_t grid_for(uint64_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
 
 constexpr int kEmitBatch = 4;              // survivors per lane in flight together in k_emit_words
 
-int launch_emit(vc_ctx *ctx, StepBuf &sb, hipStream_t st)
+// start / stop: events that are to carry the launch's own begin and end (its packet's signals, hipExtLaunchKernelGGL), or null
+int launch_emit(vc_ctx *ctx, StepBuf &sb, hipStream_t st, hipEvent_t start = nullptr, hipEvent_t stop = nullptr)
 {
     const EmitParams &e = sb.emit;
     const dim3 eg((e.ngroups + 3) / 4), block(kBlock);
+#define VC_EMIT(kernel, grid) hipExtLaunchKernelGGL((kernel), grid, block, 0, st, start, stop, 0, e)
     if (sb.busy && ctx->emit_lanes) {
         const dim3 bg(256u * (uint32_t)ctx->emit_waves_per_cu / 4u);
-        if (e.lut && sb.allseen) hipLaunchKernelGGL((k_emit_busy<true, true, 8>), bg, block, 0, st, e);
-        else if (e.lut) hipLaunchKernelGGL((k_emit_busy<true, false, 8>), bg, block, 0, st, e);
-        else if (sb.allseen) hipLaunchKernelGGL((k_emit_busy<false, true, 4>), bg, block, 0, st, e);
-        else hipLaunchKernelGGL((k_emit_busy<false, false, 4>), bg, block, 0, st, e);
-        VC_HIP(ctx, hipGetLastError());
-        return VC_OK;
+        if (e.lut && sb.allseen) VC_EMIT((k_emit_busy<true, true, 8>), bg);
+        else if (e.lut) VC_EMIT((k_emit_busy<true, false, 8>), bg);
+        else if (sb.allseen) VC_EMIT((k_emit_busy<false, true, 4>), bg);
+        else VC_EMIT((k_emit_busy<false, false, 4>), bg);
     }
-    if (ctx->emit_lanes) {
-        if (e.lut && sb.allseen) hipLaunchKernelGGL((k_emit_lanes<true, true, 8>), eg, block, 0, st, e);
-        else if (e.lut) hipLaunchKernelGGL((k_emit_lanes<true, false, 8>), eg, block, 0, st, e);
-        else if (sb.allseen) hipLaunchKernelGGL((k_emit_lanes<false, true, 4>), eg, block, 0, st, e);
-        else hipLaunchKernelGGL((k_emit_lanes<false, false, 4>), eg, block, 0, st, e);
+    else if (ctx->emit_lanes) {
+        if (e.lut && sb.allseen) VC_EMIT((k_emit_lanes<true, true, 8>), eg);
+        else if (e.lut) VC_EMIT((k_emit_lanes<true, false, 8>), eg);
+        else if (sb.allseen) VC_EMIT((k_emit_lanes<false, true, 4>), eg);
+        else VC_EMIT((k_emit_lanes<false, false, 4>), eg);
     }
-    else if (e.lut && sb.allseen) hipLaunchKernelGGL((k_emit_words<true, true, kEmitBatch>), eg, block, 0, st, e);
-    else if (e.lut) hipLaunchKernelGGL((k_emit_words<true, false, kEmitBatch>), eg, block, 0, st, e);
-    else if (sb.allseen) hipLaunchKernelGGL((k_emit_words<false, true, kEmitBatch>), eg, block, 0, st, e);
-    else hipLaunchKernelGGL((k_emit_words<false, false, kEmitBatch>), eg, block, 0, st, e);
+    else if (e.lut && sb.allseen) VC_EMIT((k_emit_words<true, true, kEmitBatch>), eg);
+    else if (e.lut) VC_EMIT((k_emit_words<true, false, kEmitBatch>), eg);
+    else if (sb.allseen) VC_EMIT((k_emit_words<false, true, kEmitBatch>), eg);
+    else VC_EMIT((k_emit_words<false, false, kEmitBatch>), eg);
+#undef VC_EMIT
     VC_HIP(ctx, hipGetLastError());
     return VC_OK;
 }
@@ -1043,7 +1048,7 @@ int vc_destroy(vc_ctx *ctx)
     for (uint32_t r = 0; r < kGatherRing; ++r)
         for (int i = 0; i < 3; ++i) if (ctx->gx[r][i]) (void)hipEventDestroy(ctx->gx[r][i]);
     for (uint32_t r = 0; r < kStepRing; ++r)
-        for (int i = 0; i < 2; ++i) if (ctx->step_ev[r][i]) (void)hipEventDestroy(ctx->step_ev[r][i]);
+        for (int i = 0; i < 3; ++i) if (ctx->step_ev[r][i]) (void)hipEventDestroy(ctx->step_ev[r][i]);
     release(ctx->d_axes); release(ctx->d_morph); release(ctx->d_lut); release(ctx->d_bbox); release(ctx->d_lut_tile); release(ctx->d_tbox); release(ctx->d_kbox); release(ctx->d_live); release(ctx->d_wbox); release(ctx->d_bm); release(ctx->d_blist); release(ctx->d_wlist);
     release(ctx->d_mcbits); release(ctx->d_mcx); release(ctx->d_mcwbase); release(ctx->d_mcgv); release(ctx->d_mcgt); release(ctx->d_mcgvoff);
     release(ctx->d_mcgtoff); release(ctx->d_mcfaces); release(ctx->d_mcbv); release(ctx->d_mcbvoff); release(ctx->d_mcbt); release(ctx->d_mcbtoff);
@@ -1434,6 +1439,7 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     StepBuf &sb = ctx->sb[ctx->head];
     sb.e_scan = ctx->step_ev[ctx->step_next][0];
     sb.e2 = ctx->step_ev[ctx->step_next][1];
+    sb.e_emit0 = ctx->step_ev[ctx->step_next][2];
     ctx->step_next = (ctx->step_next + 1) % kStepRing;
     sb.n = n; sb.survivors = 0; sb.want_vm = want_vm; sb.has_first = false;
     sb.allseen = min_views == ctx->C;
@@ -1647,10 +1653,18 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
                        sb.blocksum.ptr, sb.blockoff.ptr, sb.h_total, sb.busy ? sb.busyoff.ptr : nullptr, sb.busysum.ptr,
                        sb.busyblock.ptr, (uint32_t)ctx->dbg);
     VC_HIP(ctx, hipGetLastError());
+    // the two events a pipelined step hands from stream to stream ride on the launches in front of them where those are the
+    // list-driven ones (large grids): {scan done} on k_finish_scan, {step done} on the expansion
+    const bool want_scan_ev = !sb.no_records && (s3 != ctx->stream || sb.carve_timed);
+    const bool ride = ctx->launch_events && !sb.no_records;
+    sb.emit_ridden = ride;
+    bool scan_ridden = false;
     if (sb.busy) {
         // level 2 of both scans + the list in one launch (k_scan_groups has left the count in busyblock[0] when nscan == 1)
-        hipLaunchKernelGGL(k_finish_scan, dim3(grid_for(ngroups)), block, 0, s2, sb.blocksum.ptr, nscan, sb.blockoff.ptr, sb.h_total,
-                           sb.busysum.ptr, sb.busyblock.ptr, sb.groupcnt.ptr, ngroups, sb.busyoff.ptr, sb.busylist.ptr, (uint32_t)ctx->dbg);
+        scan_ridden = ride && want_scan_ev;
+        hipExtLaunchKernelGGL(k_finish_scan, dim3(grid_for(ngroups)), block, 0, s2, nullptr, scan_ridden ? sb.e_scan : nullptr, 0,
+                              (const uint64_t *)sb.blocksum.ptr, nscan, sb.blockoff.ptr, sb.h_total, (const uint32_t *)sb.busysum.ptr, sb.busyblock.ptr,
+                              (const uint32_t *)sb.groupcnt.ptr, ngroups, (const uint32_t *)sb.busyoff.ptr, sb.busylist.ptr, (uint32_t)ctx->dbg);
         VC_HIP(ctx, hipGetLastError());
     } else if (nscan > 1) {
         hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(kScanThreads), 0, s2, sb.blocksum.ptr, nscan, sb.blockoff.ptr, sb.h_total);
@@ -1687,21 +1701,22 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     e.dbg = (uint32_t)ctx->dbg;
     sb.emit_timed = false;
     bool scan_recorded = false;                                  // e_scan recorded by THIS step (Slot::carve_pending may still be set by an earlier one)
-    if (!sb.no_records && (s3 != ctx->stream || sb.carve_timed)) {
-        VC_HIP(ctx, hipEventRecord(sb.e_scan, ctx->stream));     // cross-stream dependency; with e2 it also brackets the expansion
+    if (want_scan_ev) {
+        if (!scan_ridden) VC_HIP(ctx, hipEventRecord(sb.e_scan, ctx->stream));     // cross-stream dependency
         if (s3 != ctx->stream) VC_HIP(ctx, hipStreamWaitEvent(s3, sb.e_scan, 0));
         sb.emit_timed = true;
         scan_recorded = true;
     }
     if (!sb.no_records) {
-        VC_TRY(launch_emit(ctx, sb, s3));
+        VC_TRY(launch_emit(ctx, sb, s3, ride ? sb.e_emit0 : nullptr, ride ? sb.e2 : nullptr));
+        if (ride) sb.emit_timed = true;
     }
     if (auto_exchange) {
         VC_TRY(enqueue_pack(ctx, sb));
         VC_TRY(enqueue_counts_exchange(ctx, sb));
         sb.counts_exchanged = true;
     }
-    VC_HIP(ctx, hipEventRecord(sb.e2, sb.no_records ? s2 : s3));
+    if (!ride || auto_exchange) VC_HIP(ctx, hipEventRecord(sb.e2, sb.no_records ? s2 : s3));
     if (!sb.no_records && s3 != ctx->stream) { s.e_emit = sb.e2; s.emit_pending = true; }   // the expansion reads the slot's bits / images
     // the slot's next preparation waits for the kernels of THIS step that read its bits / grids: always this step's own event
     // (a flag left set by an earlier step on the same slot must not keep that step's event in place: the preparation would
@@ -1742,6 +1757,7 @@ int vc_carve_end(vc_ctx *ctx, uint64_t *n_out)
             sb.emit.records = sb.records.ptr;
             sb.emit.capacity = sb.records.cap;
             VC_TRY(launch_emit(ctx, sb, ctx->stream));
+            sb.emit_ridden = false;
             VC_HIP(ctx, hipEventRecord(sb.e2, ctx->stream));
             VC_HIP(ctx, hipEventSynchronize(sb.e2));
         }
@@ -1758,7 +1774,9 @@ int vc_carve_end(vc_ctx *ctx, uint64_t *n_out)
             VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.compact_ms, sb.e1, sb.e2));
         }
         if (sb.emit_timed) {
-            VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.emit_ms, sb.e_scan, sb.e2));
+            // the launch's own begin .. end where they ride on it; else from {scan done}, which includes whatever the expansion
+            // stream still had to finish first
+            VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.emit_ms, sb.emit_ridden ? sb.e_emit0 : sb.e_scan, sb.e2));
             ctx->tm.emit_ms_sum += ctx->tm.emit_ms;
             ctx->tm.emit_launches += 1;
         }
@@ -1963,6 +1981,7 @@ int vc_set_option(vc_ctx *ctx, const char *name, int value)
     else if (k == "emit_lanes") ctx->emit_lanes = value != 0;
     else if (k == "overlap") ctx->overlap = value != 0;
     else if (k == "timing_detail") ctx->timing_detail = value != 0;
+    else if (k == "launch_events") ctx->launch_events = value != 0;
     else if (k == "event_scope" && value >= 0 && value <= 2) {
         if (ctx->npending) return fail(ctx, VC_ERR_ARG, "carve steps are in flight: collect them with vc_carve_end first");
         VC_HIP(ctx, hipSetDevice(ctx->device));
