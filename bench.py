@@ -37,6 +37,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP64_PEAK_TFLOPS = 78.6        # MI355X_MICROARCH.md: FP64 vector (an FMA counts as two; the projection is contraction-free, so its
+                               # own ceiling is 39.3 T mul-or-add per second -- the fraction is quoted against the spec figure)
+FLOPS_PER_PROJECTION = 52      # 52 f64 flop + 1 f64 divide per voxel-view
 LUT_BYTES_PER_VV = 4           # one packed int32 per voxel-view
 N_SLOTS = 8                    # resident frame sets (distinct byte masks); every timed step prepares its set again
 
@@ -164,6 +167,9 @@ def run_mode(eng, grp, mode, steps, warmup, multi, host_transport=None, depth=3,
     default).  lut_stream exists to measure ONE kernel against the HBM roof, so it runs on one stream with its events on.
     detail: also record the events around preparation and carve kernels (they cost the stream ~10 us each)."""
     stream = mode == "lut_stream"
+    table_free = mode == "fused_table_free"                  # not even the colour camera's table: every survivor is projected again
+    eng.set_option("fused_color_table", 0 if table_free else 1)
+    mode = "fused" if table_free else mode
     eng.set_option("lut_hier", 0 if stream else 1)
     eng.set_option("overlap", 0 if stream else overlap)
     eng.set_option("timing_detail", 1 if (detail or stream) else 0)
@@ -367,7 +373,7 @@ def main():
     results = {}
     order = [args.mode]
     if not args.only_headline and have_lut:
-        order += [m for m in ("lut", "lut_stream", "fused") if m != args.mode]
+        order += [m for m in ("lut", "lut_stream", "fused", "fused_table_free") if m != args.mode]
     for mode in order:
         dt, n_local, n_total, tm = run_mode(eng, grp, mode, args.steps, args.warmup, fresh=not args.resident_prep, **common)
         results[mode] = {"seconds": dt, "survivors": int(n_total), "survivors_this_rank": int(n_local), "tm": tm}
@@ -375,13 +381,18 @@ def main():
 
     # side measurements of the headline mode (short runs, never `value`)
     if not multi and not args.only_headline:
+        plain = run_mode(eng, grp, args.mode, short, 2, overlap=0, fresh=not args.resident_prep, **common)
         alone = run_mode(eng, grp, args.mode, short, 2, overlap=0, fresh=not args.resident_prep, detail=True, **common)
-        head["one_stream"] = {"ms_per_step": alone[0] / short * 1e3, "tm": alone[3]}
+        head["one_stream"] = {"ms_per_step": plain[0] / short * 1e3, "tm": alone[3], "tm_plain": plain[3]}
         det = run_mode(eng, grp, args.mode, short, 2, fresh=not args.resident_prep, detail=True, **common)
         head["detail"] = {"ms_per_step": det[0] / short * 1e3, "tm": det[3]}
         if not args.resident_prep:
             res = run_mode(eng, grp, args.mode, short, 2, fresh=False, **common)
             head["ms_per_step_resident_prep"] = res[0] / short * 1e3
+        if "fused" in results and args.mode != "fused":
+            fdet = run_mode(eng, grp, "fused", short, 2, fresh=not args.resident_prep, detail=True, **common)
+            results["fused"]["detail"] = {"ms_per_step": fdet[0] / short * 1e3, "tm": fdet[3], "steps": short}
+        head["detail"]["steps"] = short
     n_local_vox = eng.n_voxels
     total_vv = float(nx) * ny * nz * C
     ms_per_step = head["seconds"] / args.steps * 1e3
@@ -392,6 +403,7 @@ def main():
     eng.set_option("overlap", 1)
     eng.set_option("lut_hier", 1)
     eng.set_option("gather_sync", 1)
+    eng.set_option("fused_color_table", 1)
     counts_note = None
     keep = not (multi and args.exchange == "compact")
     eng.carve_begin(slot=0, mode="lut" if args.mode == "lut_stream" else args.mode, records=keep, color_cam=cc)
@@ -417,25 +429,85 @@ def main():
     gkey = "%s_%dx%dx%d" % (args.workload, nx, ny, nz)
     golden_match = (golden[gkey]["records_sha256"] == digest and golden[gkey]["survivors"] == int(n_all)) if gkey in golden else None
 
-    # ---- roofline of the DOMINANT kernel of the timed region.  With the carve cut into culling + word + voxel + assembly
-    # launches (0.01-0.03 ms each), the largest single kernel of a step is the record expansion k_emit_busy: it writes the packed
-    # survivor list (8 B per survivor) and reads each survivor's table entry (4 B, LUT mode) besides the occupancy words --
-    # HBM-bound.  Its launches are bracketed by the two events the streams exchange anyway (vc_timing emit_ms), over the timed region.
+    # ---- roofline of the DOMINANT kernel of the timed region = the kernel with the largest summed time.  The record expansion is
+    # timed in the timed region itself (its begin / end events ride on its own launch, which costs the stream nothing); the other
+    # kernels' times come from the short side run in which every launch carries such events (2-3 us per launch: never the run
+    # `value` comes from) and the kernels count the work they actually do (vc_timing_t::work).
     tm = head["tm"]
     emit_ms = tm["emit_ms_sum"] / tm["emit_launches"] if tm["emit_launches"] else None
-    per_survivor = 8 + (4 if args.mode != "fused" else 0)
-    roof = None
-    if emit_ms:
+
+    def kernel_objects(mode, dtm, dsteps, survivors_rank, live_emit_ms, color_table=True):
+        """Per kernel kind of one mode: {avg_launch_ms, bound, algorithmic bytes or flops per launch, achieved, frac}."""
+        out = {}
+        work = {k: v / max(1, dsteps) for k, v in dtm.get("work", {}).items()}
+        for kind, kv in dtm.get("kernels", {}).items():
+            ms = kv["ms_sum"] / kv["launches"]
+            o = {"avg_launch_ms": round(ms, 4), "launches_timed": kv["launches"],
+                 "timed_by": "begin / end events on every launch of a %d-step side run (three steps in flight, as the timed region)" % dsteps}
+            fused = mode == "fused"
+            if kind == "k_emit":
+                if live_emit_ms:
+                    ms = live_emit_ms
+                    o.update({"avg_launch_ms": round(ms, 4), "launches_timed": tm["emit_launches"],
+                              "timed_by": "begin / end events riding on the launch itself, every step of the timed region"})
+                if fused and not color_table:
+                    o.update({"bound": "valu_f64", "kernel": "k_emit_busy<re-projecting> (record expansion, one float64 projection per survivor)",
+                              "alg": FLOPS_PER_PROJECTION * float(survivors_rank), "per_unit": "52 flop per survivor"})
+                else:
+                    o.update({"bound": "hbm", "kernel": "k_emit_busy<FROM_LUT> (record expansion: occupancy words -> ordered {idx, rgb, seen} records)",
+                              "alg": 12.0 * survivors_rank, "per_unit": "12 B per survivor (8 B record written + 4 B table entry read)",
+                              "units_per_launch": survivors_rank})
+            elif kind == "k_voxel_words" and fused:
+                o.update({"bound": "valu_f64", "kernel": "k_voxel_words<table-free> (exact float64 projection + mask bit of the undecided words' voxels)",
+                          "alg": FLOPS_PER_PROJECTION * work.get("projections", 0.0), "per_unit": "52 flop per projection executed (lanes that asked)",
+                          "units_per_launch": work.get("projections", 0.0)})
+            elif kind == "k_voxel_words":
+                o.update({"bound": "hbm", "kernel": "k_voxel_words<LUT> (table entry + mask bit of the undecided words' voxels)",
+                          "alg": 4.0 * work.get("table_entries", 0.0), "per_unit": "4 B per table entry read (lanes that asked)",
+                          "units_per_launch": work.get("table_entries", 0.0)})
+            elif kind == "k_brick_words":
+                o.update({"bound": "hbm", "kernel": "k_brick_words (word boxes of the listed bricks against the block grids in LDS)",
+                          "alg": 8.0 * work.get("word_boxes", 0.0), "per_unit": "8 B per word box read (cameras asked)",
+                          "units_per_launch": work.get("word_boxes", 0.0)})
+            elif kind == "k_cull_bricks":
+                o.update({"bound": "hbm", "kernel": "k_cull_bricks (brick boxes against the block grids in LDS)",
+                          "alg": 8.0 * work.get("brick_boxes", 0.0), "per_unit": "8 B per brick box read (cameras asked)",
+                          "units_per_launch": work.get("brick_boxes", 0.0)})
+            else:
+                o.update({"bound": "latency", "kernel": kind, "alg": None})
+            if o.get("alg"):
+                if o["bound"] == "hbm":
+                    ach = o["alg"] / (ms * 1e-3) / 1e9
+                    o.update({"achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                              "algorithmic_bytes_per_launch": o["alg"]})
+                else:
+                    ach = o["alg"] / (ms * 1e-3) / 1e12
+                    o.update({"achieved": round(ach, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP64_PEAK_TFLOPS, 4),
+                              "algorithmic_flops_per_launch": o["alg"]})
+            o.pop("alg", None)
+            o["traffic"] = None
+            out[kind] = o
+        return out
+
+    per_survivor = 12
+    roof, kernel_table = None, None
+    ctab = True                                              # (VC_MODE_FUSED colours from the colour camera's table by default)
+    if "detail" in head:
+        objs = kernel_objects(args.mode, head["detail"]["tm"], head["detail"]["steps"], head["survivors_this_rank"], emit_ms, ctab)
+        kernel_table = {k: v["avg_launch_ms"] for k, v in objs.items()}
+        ranked = sorted((k for k in objs if objs[k].get("frac") is not None), key=lambda k: -objs[k]["avg_launch_ms"])
+        if ranked:
+            roof = objs[ranked[0]]
+            roof["dominant_of"] = kernel_table
+    if roof is None and emit_ms:
         alg = per_survivor * float(head["survivors_this_rank"])
         ach = alg / (emit_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "k_emit_busy<%s> (record expansion: occupancy words -> ordered {idx, rgb, seen} records)" %
-                ("FROM_LUT" if args.mode != "fused" else "re-projecting"),
+        roof = {"bound": "hbm", "kernel": "k_emit_busy<FROM_LUT> (record expansion: occupancy words -> ordered {idx, rgb, seen} records)",
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                "algorithmic_bytes_per_launch": alg, "bytes_per_unit": "%d B per survivor (8 B record written%s)" %
-                (per_survivor, " + 4 B table entry read" if args.mode != "fused" else ""),
+                "algorithmic_bytes_per_launch": alg, "per_unit": "12 B per survivor (8 B record written + 4 B table entry read)",
                 "units_per_launch": head["survivors_this_rank"], "avg_launch_ms": round(emit_ms, 4),
-                "timed_by": "HIP events e_scan (carve stream) .. e2 (expansion stream) of every timed step"}
-    elif multi and tm["gathers"]:
+                "timed_by": "begin / end events riding on the launch itself, every step of the timed region"}
+    elif roof is None and multi and tm["gathers"]:
         # a rank of a communicator expands the gathered words of ALL ranks (k_emit_lanes<INDIRECT>) inside vc_allgather
         g_ms = tm["gather_ms_sum"] / tm["gathers"]
         x_ms = tm["exchange_ms"]
@@ -444,6 +516,15 @@ def main():
         roof = {"bound": "hbm", "kernel": "k_emit_lanes<INDIRECT> (expansion of all ranks' occupancy words on every rank)",
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                 "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(g_ms - x_ms, 4)}
+    # Mode F: the table-free kernel against the FP64 vector peak, from the fused leg's side run
+    roof_fused = None
+    fd = head.get("detail") if args.mode == "fused" else results.get("fused", {}).get("detail")
+    if fd:
+        fobjs = kernel_objects("fused", fd["tm"], fd["steps"], head["survivors_this_rank"], None, ctab)
+        cand = [o for o in fobjs.values() if o.get("bound") == "valu_f64"]
+        if cand:
+            roof_fused = max(cand, key=lambda o: o["avg_launch_ms"])
+            roof_fused["step_kernel_times_ms"] = {k: v["avg_launch_ms"] for k, v in fobjs.items()}
     # the contract's own figure for the whole step (4 B per voxel-view + 8 B per survivor + the masks): how much
     # of the table the hierarchy never touches -- a skip factor, not a bandwidth
     contract_bytes = LUT_BYTES_PER_VV * total_vv + 8.0 * head["survivors"] + C * H * W
@@ -470,8 +551,12 @@ def main():
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(traffic_file) and roof is not None:
         tj = json.load(open(traffic_file))
-        t = tj.get("emit_%s_%s_g%d" % (args.mode, gkey, grp.world))
+        kname = roof["kernel"].split("<")[0].split(" ")[0]
+        t = tj.get("%s_%s_%s_g%d" % (kname, args.mode, gkey, grp.world)) or \
+            (tj.get("emit_%s_%s_g%d" % (args.mode, gkey, grp.world)) if kname == "k_emit_busy" else None)
         if t:
+            t = dict(t)
+            t["from"] = "profiles/ (rocprofv3 --pmc passes of an earlier session of this round), NOT measured in this run"
             roof["traffic"] = t
             gbs = t["hbm_bytes"] / (roof["avg_launch_ms"] * 1e-3) / 1e9
             roof["traffic_rate_gbs"] = round(gbs, 1)
@@ -495,21 +580,30 @@ def main():
             "frame_set_prep_on_device": round(d["prep_ms_sum"] / max(1, d["preps_timed"]), 4),
             "carve_kernels": round(d["carve_ms_sum"] / max(1, d["carve_launches"]), 4),
             "carve_kernels_one_stream": round(o["carve_ms_sum"] / max(1, o["carve_launches"]), 4),
-            "record_expansion_one_stream": round(o["emit_ms_sum"] / max(1, o["emit_launches"]), 4),
+            "record_expansion_one_stream": round(head["one_stream"]["tm_plain"]["emit_ms_sum"] / max(1, head["one_stream"]["tm_plain"]["emit_launches"]), 4),
             "ms_per_step_one_stream": round(head["one_stream"]["ms_per_step"], 4),
             "ms_per_step_with_kernel_events": round(head["detail"]["ms_per_step"], 4),
-            "note": "prep / carve figures come from a short extra run with the events around those kernels switched on "
-                    "(timing_detail): an event between two kernels costs the stream ~10 us, so the run `value` comes from "
-                    "records only the two events the streams exchange anyway"})
+            "note": "prep / carve / per-kernel figures come from short extra runs with timing_detail on (events around the phases, "
+                    "begin / end events on every launch, work counters): that costs a step 20-50 us, so the run `value` comes "
+                    "from carries only the expansion's own two events"})
     if head.get("ms_per_step_resident_prep") is not None:
         phases["ms_per_step_with_frame_sets_prepared_once"] = round(head["ms_per_step_resident_prep"], 4)
     # the same kernel without the other stream's kernels beside it (short one-stream side run): how fast it is by itself
-    if roof is not None and "one_stream" in head and roof.get("algorithmic_bytes_per_launch") and "k_emit_busy" in roof["kernel"]:
+    if roof is not None and "one_stream" in head and "dominant_of" in roof:
         o = head["one_stream"]["tm"]
-        if o["emit_launches"]:
-            alone_ms = o["emit_ms_sum"] / o["emit_launches"]
+        kind = max(roof["dominant_of"], key=lambda k: roof["dominant_of"][k] if kernel_table and objs[k].get("frac") is not None else -1.0)
+        kv = o.get("kernels", {}).get(kind)
+        if kind == "k_emit":                                   # (its events ride on its launch in every run: the plain one-stream run has it undisturbed)
+            op = head["one_stream"]["tm_plain"]
+            kv = {"ms_sum": op["emit_ms_sum"], "launches": op["emit_launches"]}
+        if kv and kv["launches"]:
+            alone_ms = kv["ms_sum"] / kv["launches"]
             roof["avg_launch_ms_alone"] = round(alone_ms, 4)
-            roof["frac_alone"] = round(roof["algorithmic_bytes_per_launch"] / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            per_launch = roof.get("algorithmic_bytes_per_launch") or roof.get("algorithmic_flops_per_launch")
+            scale = 1e9 * HBM_PEAK_GBS if roof["bound"] == "hbm" else 1e12 * FP64_PEAK_TFLOPS
+            roof["frac_alone"] = round(per_launch / (alone_ms * 1e-3) / scale, 4)
+        phases["kernels_one_stream"] = {k: round(v["ms_sum"] / v["launches"], 4) for k, v in o.get("kernels", {}).items()}
+        phases["kernels_pipelined"] = kernel_table
     out = {
         "metric": "Mvoxel-views/s (grid N^3 x 4 cams)", "value": round(value, 1), "unit": "Mvoxel-views/s",
         "n_gpus": grp.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -525,7 +619,13 @@ def main():
                    "steps_in_flight": args.depth, "exchange": transport_note, "rccl_ranks": rccl_ranks, "split": split_note,
                    "survivors_per_rank": counts_note, "records_sha256_frame_set_0": digest, "survivors_frame_set_0": int(n_all),
                    "ranks_agree_on_records": bool(ranks_agree), "matches_committed_digest": golden_match},
+        "scaling_model": None if not multi else {
+            "note": "DESIGN.md section 5, an ESTIMATE made on one GPU (no N > 1 RCCL run exists from the builder's pool): every rank "
+                    "expands ALL survivors itself, so the record expansion does not divide; expected speed-up at 8 GPUs ~1x for "
+                    "workload real, ~2x for config5, ~1.2x for big2048 (BASELINE's >= 6x assumed a 1e9 voxel-views/s kernel)",
+            "expected_speedup_at_8": {"real": 1.0, "config5": 2.0, "big2048": 1.2}.get(args.workload)},
         "roofline": roof,
+        "roofline_fused": roof_fused,
         "contract_skip": skip,
         "roofline_stream": roof_stream,
         "other_modes": others,

@@ -54,6 +54,21 @@ enum {
 #define VC_MAX_CAMERAS 16
 #define VC_UNIQUE_ID_BYTES 128
 
+typedef enum {
+    VC_K_PREP_PACK = 0, VC_K_PREP_GRID, VC_K_CULL_BRICKS, VC_K_BRICK_WORDS, VC_K_VOXEL_WORDS, VC_K_ASSEMBLE,
+    VC_K_SCAN_GROUPS, VC_K_FINISH_SCAN, VC_K_EMIT, VC_K_CARVE_ONE_LAUNCH /* k_lut_refine, k_carve_fused*, k_carve_generic, k_lut_first */,
+    VC_K_CULL /* in front of a one-launch kernel */, VC_K_COUNT_GROUPS
+} vc_kernel_kind;
+#define VC_KERNEL_KINDS 12
+enum {
+    VC_WORK_WORD_BOXES = 0,   /* 8-byte word boxes k_brick_words read (listed bricks x 64 words x cameras asked)           */
+    VC_WORK_TABLE_ENTRIES,    /* 4-byte table entries the per-voxel level read (VC_MODE_LUT)                                */
+    VC_WORK_PROJECTIONS,      /* float64 projections the per-voxel level did (VC_MODE_FUSED)                                */
+    VC_WORK_EMIT_PROJECTIONS, /* float64 projections the record expansion did (VC_MODE_FUSED without the colour table)      */
+    VC_WORK_BRICK_BOXES       /* 8-byte brick boxes k_cull_bricks read                                                      */
+};
+#define VC_WORK_KINDS 8
+
 typedef struct {
     float carve_ms;     /* the carve kernels alone (HIP events on the context's stream).  carve_ms, first_ms, compact_ms
                            and prep_ms are measured for vc_carve calls and, with option timing_detail = 1, for
@@ -77,9 +92,16 @@ typedef struct {
     float prep_ms_sum;  /* summed since vc_timing_reset                                  */
     uint32_t preps;     /* carve steps that had to prepare their frame set since vc_timing_reset */
     uint32_t preps_timed; /* ... of which prep_ms_sum holds the time                     */
-    float emit_ms;      /* record expansion of the last step (events the two streams exchange anyway) */
+    float emit_ms;      /* record expansion of the last step: the launch's own begin .. end (the events ride on the launch) */
     float emit_ms_sum;  /* summed since vc_timing_reset                                  */
     uint32_t emit_launches;
+    /* Option timing_detail = 1: every kernel of a step carries its own begin / end events (on its launch: no extra packet on
+     * the stream) and the kernels count the work they do.  Index = vc_kernel_kind; summed since vc_timing_reset. */
+    float kernel_ms_sum[VC_KERNEL_KINDS];
+    uint32_t kernel_launches[VC_KERNEL_KINDS];
+    /* work[VC_WORK_*]: what the kernels of those steps actually touched (counted on the device, lanes that really asked);
+     * valid when no step is in flight */
+    uint64_t work[VC_WORK_KINDS];
 } vc_timing_t;
 
 /* ---- lifetime ------------------------------------------------------------------ */
@@ -197,8 +219,9 @@ int vc_fetch_mesh(vc_ctx *ctx, float *verts, uint32_t *faces);
  *                   cull (1)  the one-launch kernels on tile words skip whole bricks too (k_cull); 0 also switches `bricks` off
  *                   fused_hier (1), fused_boxes (1), fused_f32box (1)  table-free kernel: word rejection; boxes read /
  *                                  bounded on the fly in float32 / float64 intervals
- *                   fused_color_table (0)  table-free carve, survivors coloured from the colour camera's table (4 B per
- *                                  voxel of the whole grid, one camera) instead of by projecting each of them again
+ *                   fused_color_table (1)  table-free carve, survivors coloured from the colour camera's table (4 B per
+ *                                  voxel of the whole grid, ONE camera, projected at the first step that wants it) instead of
+ *                                  by projecting each of them again; 0: no table of any kind (the expansion is then FP64-bound)
  *                   refine_pair (1), reorder (1)  two cameras per round trip; most selective camera first
  *                   voxel_pairs (0)  per-voxel level of the brick pipeline: 0 = two cameras per round trip up to 4 cameras, one
  *                                  above; 1 = always two; 2 = always one
@@ -216,7 +239,14 @@ int vc_fetch_mesh(vc_ctx *ctx, float *verts, uint32_t *faces);
  *                                  too -- WRONG results on purpose, to time the levels apart (scripts/exp_bricks.py); bit 2:
  *                                  no word-level tests, every word of a listed brick goes to the per-voxel level (right results)
  *   timing          timing_detail (0)  1: vc_carve_begin steps record the events around preparation and carve kernels too
- *                                  (vc_carve always does; see vc_timing_t)
+ *                                  (vc_carve always does; see vc_timing_t), every kernel carries begin / end events on its own
+ *                                  launch (kernel_ms_sum) and counts its work (vc_timing_t::work)
+ *                   kernel_events (0)  1: only the per-launch begin / end events (kernel_ms_sum), nothing else changes
+ *   streams         stream_priority (1)  carve + preparation streams at the highest queue priority, the expansion stream at
+ *                                  the lowest (the expansion fills every wave slot; the carve chain is a row of short launches
+ *                                  that would queue behind it); launch_events (1)  the events the streams exchange ride on
+ *                                  the launches in front of them; event_scope (1)  those events release to the device only;
+ *                                  reserve_cus (0)  k compute units per XCD kept out of the expansion stream's CU mask
  *   multi-GPU       gather_compact (1)  exchange occupancy words instead of records;
  *                   gather_sync (1)  0: vc_allgather returns once its work is queued (two gathers may be in flight; a read-back,
  *                                  vc_timing or vc_synchronize waits for them; vc_fetch_gathered returns the last one's list)

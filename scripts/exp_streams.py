@@ -35,7 +35,7 @@ for s in range(NS):
     eng.upload_frame(1, np.roll(frames[1], 3 * s, axis=1), slot=s)
 if mode == "lut":
     eng.build_lut()
-DEFAULTS = {"stream_priority": 1, "reserve_cus": 0, "emit_waves_per_cu": 256, "overlap": 1, "event_scope": 1, "dbg": 0, "launch_events": 1}
+DEFAULTS = {"stream_priority": 1, "reserve_cus": 0, "emit_waves_per_cu": 256, "overlap": 1, "event_scope": 1, "dbg": 0, "launch_events": 1, "kernel_events": 0, "timing_detail": 0}
 
 
 def run(n, depth=3):
@@ -75,5 +75,8 @@ for rep in range(4):
         emit = tm["emit_ms_sum"] / max(1, tm["emit_launches"])
         best[s] = min(best[s], dt)
         print("rep %d %-44s step %.4f ms  emit %.4f ms" % (rep, s, dt, emit), flush=True)
+        if rep == 3 and tm["kernels"]:
+            print("      " + "  ".join("%s %.1f" % (k[2:], v["ms_sum"] / v["launches"] * 1e3) for k, v in tm["kernels"].items()), " us;  work per step:",
+                  {k: v // 220 for k, v in tm["work"].items() if v}, flush=True)
 for s in settings:
     print("BEST %-44s %.4f ms" % (s, best[s]), flush=True)

@@ -169,7 +169,7 @@ def test_every_kernel_family_agrees_with_oracle(eng, seed):
     eng.upload_frame(2, frames3[2])
     eng.build_lut()
     try:
-        for opts in ({"lut_hier": 1}, {"bricks": 0}, {"cull": 0}, {"lut_tile": 0}, {"fused_tile": 0}, {"fused_color_table": 1}, {"fused_boxes": 0}, {"fused_boxes": 0, "fused_f32box": 0},
+        for opts in ({"lut_hier": 1}, {"bricks": 0}, {"cull": 0}, {"lut_tile": 0}, {"fused_tile": 0}, {"fused_color_table": 0}, {"fused_boxes": 0}, {"fused_boxes": 0, "fused_f32box": 0},
                      {"fused_boxes": 0, "fused_tile": 0}, {"lut_hier": 0}, {"lut_hier": 0, "first_kv": 4}, {"lut_hier": 1, "refine_b": 16, "refine_pair": 0},
                      {"reorder": 0}, {"fused_hier": 0}, {"refine_pair": 0}, {"emit_lanes": 0}, {"emit_busy": 2}, {"emit_busy": 2, "lut_tile": 0, "fused_tile": 0},
                      {"grid_lds_kb": 64}, {"grid_lds_kb": 148, "voxel_pairs": 2}, {"voxel_pairs": 1},     # 1024-thread workgroups, coarse brick grids
@@ -187,11 +187,11 @@ def test_every_kernel_family_agrees_with_oracle(eng, seed):
                 assert np.array_equal(eng.fetch_occupancy(), occ), (opts, mode)
                 assert int(np.bitwise_count(eng.pack_entries()[:, 0]).sum()) == want["count"], (opts, mode)
             for k in opts:
-                eng.set_option(k, {"lut_hier": 1, "bricks": 1, "cull": 1, "lut_tile": 1, "fused_tile": 1, "fused_f32box": 1, "fused_boxes": 1, "fused_color_table": 0, "first_kv": 1, "refine_b": 8, "reorder": 1, "fused_hier": 1, "refine_pair": 1, "emit_lanes": 1, "emit_busy": 1, "force_generic": 0, "grid_lds_kb": 0, "voxel_pairs": 0}[k])
+                eng.set_option(k, {"lut_hier": 1, "bricks": 1, "cull": 1, "lut_tile": 1, "fused_tile": 1, "fused_f32box": 1, "fused_boxes": 1, "fused_color_table": 1, "first_kv": 1, "refine_b": 8, "reorder": 1, "fused_hier": 1, "refine_pair": 1, "emit_lanes": 1, "emit_busy": 1, "force_generic": 0, "grid_lds_kb": 0, "voxel_pairs": 0}[k])
             if "grid_lds_kb" in opts:
                 eng.touch_masks(0)
     finally:
-        for k, v in {"lut_hier": 1, "bricks": 1, "cull": 1, "lut_tile": 1, "fused_tile": 1, "fused_f32box": 1, "fused_boxes": 1, "fused_color_table": 0, "first_kv": 1, "refine_b": 8, "reorder": 1, "fused_hier": 1, "refine_pair": 1, "emit_lanes": 1, "emit_busy": 1, "force_generic": 0, "grid_lds_kb": 0, "voxel_pairs": 0}.items():
+        for k, v in {"lut_hier": 1, "bricks": 1, "cull": 1, "lut_tile": 1, "fused_tile": 1, "fused_f32box": 1, "fused_boxes": 1, "fused_color_table": 1, "first_kv": 1, "refine_b": 8, "reorder": 1, "fused_hier": 1, "refine_pair": 1, "emit_lanes": 1, "emit_busy": 1, "force_generic": 0, "grid_lds_kb": 0, "voxel_pairs": 0}.items():
             eng.set_option(k, v)
     with pytest.raises(Exception):
         eng.set_option("no_such_option", 1)
@@ -1086,6 +1086,16 @@ def test_index_width_at_the_u32_limit(eng, cams, masks, frames):
             hi = idx.size
         assert np.array_equal(idx[lo:hi], want["idx"])
         assert np.array_equal(rec[lo:hi].view(np.uint8).reshape(-1, 8)[:, 4:7][:, ::-1], want["bgr"])
+    # the default colours the survivors from the colour camera's table over the whole grid (17 GB here); without it every
+    # survivor is projected again: the same records
+    first = hashlib.sha256(rec.tobytes()).digest()             # (the pinned buffer is reused by the next fetch)
+    eng.set_option("fused_color_table", 0)
+    try:
+        assert eng.carve(mode="fused") == n
+        rec = eng.fetch_records(pinned=True)
+        assert hashlib.sha256(rec.tobytes()).digest() == first
+    finally:
+        eng.set_option("fused_color_table", 1)
     eng.set_slab(1000, 1023)                                   # a slab that ends at the last voxel
     m = eng.carve(mode="fused")
     tail = eng.fetch_records()

@@ -52,7 +52,14 @@ def test_bench_contract_single_gpu(built):
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert d["config"]["survivors"] == 461113                      # the 256^3 golden count: the bench ran the real path
-    assert r["frac"] <= 1.0 and "k_emit_busy" in r["kernel"] and r["avg_launch_ms"] > 0
+    assert r["frac"] <= 1.0 and r["avg_launch_ms"] > 0 and r["kernel"].startswith("k_")
+    # the roofline names the kernel with the largest time of the step, whichever it is at this size, out of the per-kernel table
+    assert max(r["dominant_of"].values()) >= r["avg_launch_ms"] * 0.5 and "k_emit" in r["dominant_of"]
+    # Mode F: the table-free projection kernel against the FP64 vector peak
+    f = d["roofline_fused"]
+    assert f["bound"] == "valu_f64" and f["unit"] == "TFLOP/s" and 0 < f["frac"] <= 1.0 and f["units_per_launch"] > 0
+    assert abs(f["algorithmic_flops_per_launch"] - 52 * f["units_per_launch"]) < 1 and abs(f["frac"] - f["achieved"] / f["peak"]) < 1e-3
+    assert set(d["other_modes"]) >= {"fused", "fused_table_free", "lut_stream"}
     assert d["contract_skip"]["skip_factor_vs_hbm_peak"] > 0
     # the device's record list of frame set 0 is the CPU oracle's, byte for byte (the baseline leg carved the whole grid)
     assert c["device_records_match"] is True and c["records_sha256"] == d["config"]["records_sha256_frame_set_0"]

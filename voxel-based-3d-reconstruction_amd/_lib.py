@@ -29,6 +29,12 @@ c_f64p = ctypes.POINTER(ctypes.c_double)
 c_ctx = ctypes.c_void_p
 
 
+VC_KERNEL_KINDS, VC_WORK_KINDS = 12, 8
+KERNEL_KINDS = ("k_prep_pack", "k_prep_grid", "k_cull_bricks", "k_brick_words", "k_voxel_words", "k_assemble", "k_scan_groups",
+                "k_finish_scan", "k_emit", "one_launch_carve", "k_cull", "k_count_groups")
+WORK_KINDS = ("word_boxes", "table_entries", "projections", "emit_projections", "brick_boxes")
+
+
 class VcTiming(ctypes.Structure):
     _fields_ = [("carve_ms", ctypes.c_float), ("compact_ms", ctypes.c_float),
                 ("gather_ms", ctypes.c_float), ("lut_ms", ctypes.c_float),
@@ -39,7 +45,9 @@ class VcTiming(ctypes.Structure):
                 ("gather_ms_sum", ctypes.c_float), ("gathers", ctypes.c_uint32),
                 ("prep_ms", ctypes.c_float), ("prep_ms_sum", ctypes.c_float), ("preps", ctypes.c_uint32),
                 ("preps_timed", ctypes.c_uint32), ("emit_ms", ctypes.c_float), ("emit_ms_sum", ctypes.c_float),
-                ("emit_launches", ctypes.c_uint32)]
+                ("emit_launches", ctypes.c_uint32),
+                ("kernel_ms_sum", ctypes.c_float * VC_KERNEL_KINDS), ("kernel_launches", ctypes.c_uint32 * VC_KERNEL_KINDS),
+                ("work", ctypes.c_uint64 * VC_WORK_KINDS)]
 
 
 # name -> (restype, argtypes); every symbol include/voxcarve.h declares.

@@ -139,6 +139,7 @@ struct CarveParams {
     uint32_t nx, ny, nz, z0;
     uint32_t C, H, W, mwords;
     uint32_t min_views;
+    unsigned long long *stats;  // option timing_detail: work counters (stat_add), else null
     uint32_t dbg;               // experiments only (vc_set_option("dbg", ...), scripts/exp_bricks.py): 1 = skip the voxel level (undecided words
                                 // count as alive), 2 = skip the word level too; 8 = preparation, carve and scan kernels launch and return
                                 // at once (32 / 64 / 128 / 256 / 512: only the preparation / cull + word level / voxel level /
@@ -169,6 +170,7 @@ struct EmitParams {
     uint32_t nx, ny, z0;
     uint32_t H, W;
     int has_cam;
+    unsigned long long *stats;  // option timing_detail: work counters, else null
     uint32_t dbg;               // experiments only (see CarveParams::dbg): 16 = the expansion launches and returns
     CamDev cam;
 };
@@ -1153,6 +1155,12 @@ __global__ __launch_bounds__(kBlock) void k_cull(const CarveParams p)
 constexpr uint32_t kShards = 64;
 constexpr uint32_t kWideBlock = 1024;  // k_cull_bricks / k_brick_words run 256 or 1024 threads per workgroup (large grids: 16 waves share one LDS copy)
 constexpr uint32_t kShardStride = 32;   // u32 between two shard counters: one 128-byte line each (atomics on one LINE serialise too)
+// Work counters of the detail runs (vc_timing_t::work): one wave-level add per wave and kind, on kShards lines of their own.
+constexpr uint32_t kStatStride = 16;    // u64 between two shards of a counter: one 128-byte line each
+__device__ __forceinline__ void stat_add(unsigned long long *stats, uint32_t kind, uint32_t wave, uint32_t lane, uint64_t v)
+{
+    if (stats && lane == 0 && v) atomicAdd(&stats[((size_t)kind * kShards + (wave % kShards)) * kStatStride], (unsigned long long)v);
+}
 struct BrickLists {
     uint32_t *counters;         // [2][3][kShards * kShardStride]: bricks, columns, words, of this parity; k_cull_bricks zeroes the other set
     uint32_t *bricks;           // brick numbers (live, not full)
@@ -1215,6 +1223,7 @@ __global__ __launch_bounds__(kWideBlock) void k_cull_bricks(const CarveParams p,
     // a wave takes 64 bricks at a time; a brick column has tq of them: 64 / tq whole columns per wave (ny <= 1024), or one column
     // in tq / 64 rounds (ny = 2048, 4096), so that a column is listed once, by one wave
     const uint32_t ipw = p.tq > 64u ? p.tq / 64u : 1u;
+    uint64_t nstat = 0;
     for (uint32_t W = wave0; W * ipw < nw; W += nwaves) {
         uint64_t colany = 0;
         for (uint32_t it = 0; it < ipw; ++it) {
@@ -1223,6 +1232,7 @@ __global__ __launch_bounds__(kWideBlock) void k_cull_bricks(const CarveParams p,
             bool cand = b < nbricks, full = true;
             for (uint32_t q0 = 0; q0 < p.C && __ballot(cand) != 0; q0 += 4) {
                 uint64_t bb[4];
+                if (p.stats) nstat += (uint64_t)__popcll(__ballot(cand)) * (p.C - q0 < 4u ? p.C - q0 : 4u);
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     bb[k] = (q0 + k < p.C && cand) ? p.kbox[(size_t)ord(s_order, q0 + k) * p.nbrick_pad + b] : 0ull;
@@ -1255,6 +1265,7 @@ __global__ __launch_bounds__(kWideBlock) void k_cull_bricks(const CarveParams p,
         const uint32_t cat = shard_append(cnt + kShards * kShardStride, bl.cap_c, W % kShards, cm, lane);
         if (cwant) bl.columns[cat] = p.tq > 64u ? W : (W * 64) / p.tq + lane;
     }
+    stat_add(p.stats, 4 /* VC_WORK_BRICK_BOXES */, wave0, lane, nstat);
 }
 
 // Once per grid / slab / camera set: the tile words' pixel boxes in brick-major order (brick b, lane (q, l): row quad
@@ -1304,6 +1315,7 @@ __global__ __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu(8, 8
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t nwaves = gridDim.x * (blockDim.x / 64);
     const uint32_t qpl = p.nx >> 2, nzl = (uint32_t)(p.n / ((uint64_t)p.nx * p.ny));
+    uint64_t nstat = 0;
     for (uint32_t t = wave0; t < nlist; t += nwaves) {
         uint32_t shard, within, ssize;
         shard_locate(sv, t, shard, within, ssize);
@@ -1316,6 +1328,7 @@ __global__ __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu(8, 8
         for (uint32_t q0 = 0; q0 < p.C && __ballot(cand) != 0 && !(p.dbg & 6u); q0 += 4) {
             uint64_t bb[4];
             uint32_t cn[4];
+            if (p.stats) nstat += (uint64_t)__popcll(__ballot(cand)) * (p.C - q0 < 4u ? p.C - q0 : 4u);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 cn[k] = q0 + k < p.C ? ord(s_order, q0 + k) : 0u;
@@ -1341,6 +1354,7 @@ __global__ __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu(8, 8
             if (need) bl.words[o] = T | ((uint64_t)need << 32);
         }
     }
+    stat_add(p.stats, 0 /* VC_WORK_WORD_BOXES */, wave0, lane, nstat);
 }
 
 // B undecided words per wave (list entries B t .. B t + B - 1), lanes = the 64 voxels of a tile word (4 x-rows x 16 y).
@@ -1356,6 +1370,7 @@ __global__ __launch_bounds__(kBlock) void k_voxel_words(const CarveParams p, con
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
     const uint32_t nwaves = gridDim.x * (kBlock / 64);
     const uint32_t qpl = p.nx >> 2;
+    uint64_t nstat = 0;
     for (uint32_t t = wave0; t < nbatch; t += nwaves) {
         // lane b < B fetches entry b of the batch; everybody gets them by cross-lane reads
         uint32_t shard, within, ssize;
@@ -1394,6 +1409,7 @@ __global__ __launch_bounds__(kBlock) void k_voxel_words(const CarveParams p, con
                     // (table entries are read once per step: streamed past the caches, which keep the mask bits)
                     off[b] = t1 ? __builtin_nontemporal_load(&L1[(size_t)Tb[b] * 64]) : -2;
                     off2[b] = t2 ? __builtin_nontemporal_load(&L2[(size_t)Tb[b] * 64]) : -2;
+                    if (p.stats) nstat += (uint64_t)__popcll(__ballot(t1)) + (uint64_t)__popcll(__ballot(t2));
                 }
 #pragma unroll
                 for (int b = 0; b < B; ++b) {
@@ -1414,6 +1430,7 @@ __global__ __launch_bounds__(kBlock) void k_voxel_words(const CarveParams p, con
                 bool ok = true;
                 for (uint32_t left = nd[b]; left; left &= left - 1) {
                     const uint32_t c = (uint32_t)__builtin_ctz(left);
+                    if (p.stats) nstat += (uint64_t)__popcll(__ballot(ok));
                     if (ok) {
                         double u, v;
                         project_point(p.cam[c], VX, VY, VZ, u, v);
@@ -1433,6 +1450,7 @@ __global__ __launch_bounds__(kBlock) void k_voxel_words(const CarveParams p, con
         }
         if (mine_valid) bl.bm[(uint32_t)e0] = mine;
     }
+    stat_add(p.stats, LUT ? 1 /* VC_WORK_TABLE_ENTRIES */ : 2 /* VC_WORK_PROJECTIONS */, wave0, lane, nstat);
 }
 
 // One wave per (listed brick column, layer): the 4 / qpg groups (4096 consecutive voxels = 64 tile words each) that lie
@@ -2412,6 +2430,7 @@ __device__ __forceinline__ void emit_group_lanes(const EmitParams &p, const uint
             emit_prepare<FROM_LUT, EB, INDIRECT>(p, nz, h.mine, h.mybase, wstart, tbase, gw, lane, A, rowwords, wix, wiy, wiz);
             emit_finish<ALLSEEN, EB, INDIRECT>(p, h.out0, gw, lane, A);
         }
+        if (p.has_cam) stat_add(p.stats, 3 /* VC_WORK_EMIT_PROJECTIONS */, g, lane, wstart);   // (every survivor of the group was projected)
         return;
     }
     EmitBatch<EB> B;

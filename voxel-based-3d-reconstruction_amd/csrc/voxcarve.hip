@@ -155,6 +155,11 @@ struct StepBuf {
     hipEvent_t e0 = nullptr, e_first = nullptr, e1 = nullptr, e_prep = nullptr;
     hipEvent_t e2 = nullptr, e_scan = nullptr, e_emit0 = nullptr;   // borrowed from vc_ctx::step_ev for the step in this set (see there)
     bool emit_ridden = false;                // e_emit0 / e2 are the expansion launch's own begin and end
+    // option timing_detail: begin / end events of this step's kernels by kind (owned, made on first use; they ride on the launches),
+    // which pair each kind used (the expansion and k_finish_scan may carry the step's own events instead), and which kinds ran
+    hipEvent_t kev[VC_KERNEL_KINDS][2] = {};
+    hipEvent_t kused[VC_KERNEL_KINDS][2] = {};
+    uint32_t kmask = 0;
     bool prepped = false, prep_timed = false; // this step queued preparation kernels in front of its carve (timed: e_prep .. e0)
     bool carve_timed = false;                // e0 / e1 were recorded around the carve kernels (synchronous calls, timing_detail)
     bool emit_timed = false;                 // e_scan / e2 bracket the record expansion
@@ -260,7 +265,7 @@ struct vc_ctx {
     int lut_tile = 1;                // hierarchical LUT kernel on tile words (needs nx % 4 == 0, ny % 64 == 0)
     int fused_tile = 1;              // the same word shape for the hierarchical table-free kernel
     int fused_f32box = 1;            // its word boxes from float32 intervals after a float64 rigid transform ...
-    int fused_color_table = 0;       // VC_MODE_FUSED: colour the survivors from the colour camera's table (one camera, whole grid)
+    int fused_color_table = 1;       // VC_MODE_FUSED: colour the survivors from the colour camera's table (one camera, whole grid; 0: project each survivor again)
     int fused_boxes = 1;             // ... or read from boxes reduced once from the exact pixels (no table involved)
     bool lut_valid = false;          // vc_build_lut ran for this grid / slab / cameras (tile-ordered table, or y-major where tiles do not apply)
     uint32_t upload_mask = 0;        // cameras handed in by vc_upload_lut so far
@@ -282,6 +287,7 @@ struct vc_ctx {
     int fused_hier = 1;              // VC_MODE_FUSED: interval-arithmetic word rejection (needs ny % 64 == 0)
     int lut_hier = 1;                // VC_MODE_LUT: hierarchical kernel (boxes + block grid) instead of stream + refine
     int timing_detail = 0;           // also time preparation and carve kernels of pipelined steps (three more events on the carve stream)
+    int kernel_events = 0;           // every launch of a step carries begin / end events of its own (no packet of their own: vc_timing_t::kernel_ms_sum)
     bool sync_call = false;          // inside vc_carve: the step is collected at once, events between its kernels cost nothing that matters
     DevBuf<uint16_t> d_viewmask;
     DevBuf<double> d_scratch;
@@ -318,6 +324,8 @@ struct vc_ctx {
     int lut_color_cam = -1;
 
     vc_timing_t tm;
+    StepBuf *kev_sb = nullptr;       // timing_detail: the step whose kernels are being queued (their launches carry its per-kind events)
+    DevBuf<unsigned long long> d_stats;   // timing_detail: the kernels' work counters, [VC_WORK_KINDS][kShards][kStatStride]
 
     uint64_t n_voxels() const { return (uint64_t)nx * ny * (z1 - z0); }
     uint64_t i0() const { return (uint64_t)z0 * nx * ny; }
@@ -326,6 +334,25 @@ struct vc_ctx {
 namespace {
 
 int fail(vc_ctx *ctx, int code, const char *fmt, ...);
+
+// timing_detail: the begin / end events launch `kind` of the step being queued is to carry (null otherwise: an ordinary launch)
+void kev_pick(vc_ctx *ctx, int kind, hipEvent_t &start, hipEvent_t &stop)
+{
+    start = stop = nullptr;
+    StepBuf *sb = ctx->kev_sb;
+    if (!sb) return;
+    for (int i = 0; i < 2; ++i)
+        if (!sb->kev[kind][i] && hipEventCreate(&sb->kev[kind][i]) != hipSuccess) return;
+    start = sb->kev[kind][0]; stop = sb->kev[kind][1];
+    sb->kused[kind][0] = start; sb->kused[kind][1] = stop;
+    sb->kmask |= 1u << kind;
+}
+#define VC_KLAUNCH(kind, kernel, grid, block, lds, st, ...)                                             \
+    do {                                                                                                \
+        hipEvent_t ks_, ke_;                                                                            \
+        kev_pick(ctx, kind, ks_, ke_);                                                                  \
+        hipExtLaunchKernelGGL(kernel, grid, block, lds, st, ks_, ke_, 0, __VA_ARGS__);                  \
+    } while (0)
 
 // (Re)creates the three streams for ctx->stream_priority / ctx->reserve_cus.  Nothing may be in flight.
 hipError_t make_streams(vc_ctx *ctx)
@@ -567,15 +594,15 @@ int launch_bricks(vc_ctx *ctx, CarveParams &p, size_t lds, uint32_t ngroups)
         VC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_brick_words), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxWideLds));
         ctx->big_lds_ok = true;
     }
-    hipLaunchKernelGGL(k_cull_bricks, dim3(cull_wgs), gblock, lds, ctx->stream, p, bl, ngroups);
-    hipLaunchKernelGGL(k_brick_words, dim3(word_wgs), gblock, lds, ctx->stream, p, bl);
+    VC_KLAUNCH(VC_K_CULL_BRICKS, k_cull_bricks, dim3(cull_wgs), gblock, lds, ctx->stream, p, bl, ngroups);
+    VC_KLAUNCH(VC_K_BRICK_WORDS, k_brick_words, dim3(word_wgs), gblock, lds, ctx->stream, p, bl);
     // many cameras: most voxels fail the first camera they ask, a second camera's entries read in the same round trip would be
     // wasted on them; few cameras: two per dependent round (the lists are short, the kernel is latency bound)
     const bool pairs = !LUT || ctx->voxel_pairs == 1 || (ctx->voxel_pairs == 0 && p.C <= 4);
     const dim3 vgrid(sized(k_words, (uint64_t)p.nbrick_pad * 4, (uint64_t)p.nbrick_pad * 64, pairs ? 32 : 64));
-    if (pairs) hipLaunchKernelGGL((k_voxel_words<LUT, true>), vgrid, block, 0, ctx->stream, p, bl);
-    else hipLaunchKernelGGL((k_voxel_words<LUT, false>), vgrid, block, 0, ctx->stream, p, bl);
-    hipLaunchKernelGGL(k_assemble, dim3(sized(k_cols == 0xffffffffu ? k_cols : k_cols * 16u, (uint64_t)ncolumns * 4, (uint64_t)ncolumns * 16, 4)),
+    if (pairs) VC_KLAUNCH(VC_K_VOXEL_WORDS, (k_voxel_words<LUT, true>), vgrid, block, 0, ctx->stream, p, bl);
+    else VC_KLAUNCH(VC_K_VOXEL_WORDS, (k_voxel_words<LUT, false>), vgrid, block, 0, ctx->stream, p, bl);
+    VC_KLAUNCH(VC_K_ASSEMBLE, k_assemble, dim3(sized(k_cols == 0xffffffffu ? k_cols : k_cols * 16u, (uint64_t)ncolumns * 4, (uint64_t)ncolumns * 16, 4)),
                        block, 0, ctx->stream, p, bl);
     VC_HIP(ctx, hipGetLastError());
     return VC_OK;
@@ -706,7 +733,7 @@ int ensure_prepared(vc_ctx *ctx, Slot &s, bool want_grids, const CarveParams *cp
         pp.iters = (uint32_t)(total_words / (256ull * 1024ull));
         pp.iters = pp.iters < 1 ? 1 : (pp.iters > 16 ? 16 : pp.iters);
         const uint32_t pw = (ctx->mwords + kBlock * pp.iters - 1) / (kBlock * pp.iters), fw = (uint32_t)((HW + 4 * kBlock - 1) / (4 * kBlock));
-        hipLaunchKernelGGL(k_prep_pack, dim3(C * pw + pp.nframes * fw), dim3(kBlock), 0, st, pp);
+        VC_KLAUNCH(VC_K_PREP_PACK, k_prep_pack, dim3(C * pw + pp.nframes * fw), dim3(kBlock), 0, st, pp);
         VC_HIP(ctx, hipGetLastError());
         s.bits_valid = true;
         s.grids_valid = false;
@@ -722,7 +749,7 @@ int ensure_prepared(vc_ctx *ctx, Slot &s, bool want_grids, const CarveParams *cp
         s.counts_zero = false;
         // all grids together hold at most 16 blocks per budgeted word; every camera's blocks are rounded up to whole workgroups
         const uint32_t grid_wgs = (16u * s.budget_words + kBlock - 1) / kBlock + C;
-        hipLaunchKernelGGL(k_prep_grid, dim3(grid_wgs + est_wgs), dim3(kBlock), 0, st, p,
+        VC_KLAUNCH(VC_K_PREP_GRID, k_prep_grid, dim3(grid_wgs + est_wgs), dim3(kBlock), 0, st, p,
                            s.grid.ptr, s.boxes.ptr, s.parity, (uint32_t)ctx->grid_min_shift, s.budget_words, ns, grid_wgs);
         VC_HIP(ctx, hipGetLastError());
         // large grids (the brick pipeline's 1024-thread workgroups): the brick level gets 4 x 4 times coarser blocks
@@ -1063,7 +1090,10 @@ int vc_destroy(vc_ctx *ctx)
         if (b.e_first) (void)hipEventDestroy(b.e_first);
         if (b.e1) (void)hipEventDestroy(b.e1);
         if (b.e_prep) (void)hipEventDestroy(b.e_prep);
+        for (int kk = 0; kk < VC_KERNEL_KINDS; ++kk)
+            for (int i = 0; i < 2; ++i) if (b.kev[kk][i]) (void)hipEventDestroy(b.kev[kk][i]);
     }
+    release(ctx->d_stats);
     release(ctx->d_viewmask); release(ctx->d_scratch); release(ctx->d_counts); release(ctx->d_gathered);
     release(ctx->d_ent_all[0]); release(ctx->d_ent_all[1]); release(ctx->d_xcnt); release(ctx->d_xoff); release(ctx->d_xbsum);
     release(ctx->d_xboff); release(ctx->d_lut_color);
@@ -1475,6 +1505,16 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
 
     CarveParams p;
     fill_params(ctx, p);
+    sb.kmask = 0;
+    ctx->kev_sb = nullptr;
+    if (ctx->timing_detail || ctx->kernel_events) ctx->kev_sb = &sb;   // every launch of this step carries begin / end events
+    if (ctx->timing_detail) {                                     // ... and the kernels count their work
+        if (!ctx->d_stats.ptr) {
+            VC_TRY(ensure(ctx, ctx->d_stats, (size_t)VC_WORK_KINDS * kShards * kStatStride));
+            VC_HIP(ctx, hipMemset(ctx->d_stats.ptr, 0, ctx->d_stats.cap * sizeof(unsigned long long)));
+        }
+        p.stats = ctx->d_stats.ptr;
+    }
     p.words = sb.words.ptr;
     p.groupcnt = sb.groupcnt.ptr;
     p.viewmask = ctx->d_viewmask.ptr;
@@ -1541,14 +1581,14 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
                     if (ctx->cull && ctx->kbox_valid) {
                         p.live = ctx->d_live.ptr;
                         const uint32_t cw = p.nbrick_pad / 256;
-                        hipLaunchKernelGGL(k_cull, dim3(cw < 1 ? 1 : (cw > 1024 ? 1024 : cw)), block, lds, ctx->stream, p);
+                        VC_KLAUNCH(VC_K_CULL, k_cull, dim3(cw < 1 ? 1 : (cw > 1024 ? 1024 : cw)), block, lds, ctx->stream, p);
                     }
-                    hipLaunchKernelGGL((k_lut_refine<8, true, true, true>), rgrid, block, lds, ctx->stream, p);
+                    VC_KLAUNCH(VC_K_CARVE_ONE_LAUNCH, (k_lut_refine<8, true, true, true>), rgrid, block, lds, ctx->stream, p);
                 }
             }
-            else if (ctx->refine_pair) hipLaunchKernelGGL((k_lut_refine<8, true, true>), rgrid, block, lds, ctx->stream, p);
-            else if (ctx->refine_b == 8) hipLaunchKernelGGL((k_lut_refine<8, true, false>), rgrid, block, lds, ctx->stream, p);
-            else hipLaunchKernelGGL((k_lut_refine<16, true, false>), rgrid, block, lds, ctx->stream, p);
+            else if (ctx->refine_pair) VC_KLAUNCH(VC_K_CARVE_ONE_LAUNCH, (k_lut_refine<8, true, true>), rgrid, block, lds, ctx->stream, p);
+            else if (ctx->refine_b == 8) VC_KLAUNCH(VC_K_CARVE_ONE_LAUNCH, (k_lut_refine<8, true, false>), rgrid, block, lds, ctx->stream, p);
+            else VC_KLAUNCH(VC_K_CARVE_ONE_LAUNCH, (k_lut_refine<16, true, false>), rgrid, block, lds, ctx->stream, p);
         } else if (mode == VC_MODE_LUT) {
             const size_t lds = (size_t)ctx->mwords * sizeof(uint32_t);
             const int kv = ctx->first_kv;
@@ -1559,17 +1599,17 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
             if (per_cu < 1) per_cu = 1;
             const uint32_t fmax = 256u * per_cu;
             const dim3 fgrid((uint32_t)(fwant < fmax ? fwant : fmax)), fblock(kFirstBlock);
-            if (kv == 1) hipLaunchKernelGGL((k_lut_first<1>), fgrid, fblock, lds, ctx->stream, p);
-            else if (kv == 4) hipLaunchKernelGGL((k_lut_first<4>), fgrid, fblock, lds, ctx->stream, p);
-            else hipLaunchKernelGGL((k_lut_first<2>), fgrid, fblock, lds, ctx->stream, p);
+            if (kv == 1) VC_KLAUNCH(VC_K_CARVE_ONE_LAUNCH, (k_lut_first<1>), fgrid, fblock, lds, ctx->stream, p);
+            else if (kv == 4) VC_KLAUNCH(VC_K_CARVE_ONE_LAUNCH, (k_lut_first<4>), fgrid, fblock, lds, ctx->stream, p);
+            else VC_KLAUNCH(VC_K_CARVE_ONE_LAUNCH, (k_lut_first<2>), fgrid, fblock, lds, ctx->stream, p);
             VC_HIP(ctx, hipGetLastError());
             if (sb.carve_timed) { VC_HIP(ctx, hipEventRecord(sb.e_first, ctx->stream)); sb.has_first = true; }
             const uint64_t groups = p.n_pad / 4096;
             const uint64_t rwant = (groups + 3) / 4;
             const uint64_t rmax = 256ull * (uint64_t)ctx->refine_blocks_per_cu;
             const dim3 rgrid((uint32_t)(rwant < rmax ? rwant : rmax));
-            if (ctx->refine_b == 8) hipLaunchKernelGGL((k_lut_refine<8, false, false>), rgrid, block, 0, ctx->stream, p);
-            else hipLaunchKernelGGL((k_lut_refine<16, false, false>), rgrid, block, 0, ctx->stream, p);
+            if (ctx->refine_b == 8) VC_KLAUNCH(VC_K_CARVE_ONE_LAUNCH, (k_lut_refine<8, false, false>), rgrid, block, 0, ctx->stream, p);
+            else VC_KLAUNCH(VC_K_CARVE_ONE_LAUNCH, (k_lut_refine<16, false, false>), rgrid, block, 0, ctx->stream, p);
         }
         else if (ctx->ny % 64 == 0 && ctx->fused_hier) {
             const size_t lds = grid_lds;
@@ -1594,32 +1634,32 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
                         if (ctx->cull && ctx->kbox_valid) {
                             p.live = ctx->d_live.ptr;
                             const uint32_t cw = p.nbrick_pad / 256;
-                            hipLaunchKernelGGL(k_cull, dim3(cw < 1 ? 1 : (cw > 1024 ? 1024 : cw)), block, lds, ctx->stream, p);
+                            VC_KLAUNCH(VC_K_CULL, k_cull, dim3(cw < 1 ? 1 : (cw > 1024 ? 1024 : cw)), block, lds, ctx->stream, p);
                         }
-                        hipLaunchKernelGGL((k_carve_fused_hier<true, 2>), rgrid, block, lds, ctx->stream, p);
+                        VC_KLAUNCH(VC_K_CARVE_ONE_LAUNCH, (k_carve_fused_hier<true, 2>), rgrid, block, lds, ctx->stream, p);
                     }
                 }
-                else if (ctx->fused_f32box) hipLaunchKernelGGL((k_carve_fused_hier<true, 1>), rgrid, block, lds, ctx->stream, p);
-                else hipLaunchKernelGGL((k_carve_fused_hier<true, 0>), rgrid, block, lds, ctx->stream, p);
+                else if (ctx->fused_f32box) VC_KLAUNCH(VC_K_CARVE_ONE_LAUNCH, (k_carve_fused_hier<true, 1>), rgrid, block, lds, ctx->stream, p);
+                else VC_KLAUNCH(VC_K_CARVE_ONE_LAUNCH, (k_carve_fused_hier<true, 0>), rgrid, block, lds, ctx->stream, p);
             }
             else if (ctx->fused_boxes) {
                 VC_TRY(ensure_boxes(ctx, false));
                 p.bbox = ctx->d_bbox.ptr;
-                hipLaunchKernelGGL((k_carve_fused_hier<false, 2>), rgrid, block, lds, ctx->stream, p);
+                VC_KLAUNCH(VC_K_CARVE_ONE_LAUNCH, (k_carve_fused_hier<false, 2>), rgrid, block, lds, ctx->stream, p);
             }
-            else if (ctx->fused_f32box) hipLaunchKernelGGL((k_carve_fused_hier<false, 1>), rgrid, block, lds, ctx->stream, p);
-            else hipLaunchKernelGGL((k_carve_fused_hier<false, 0>), rgrid, block, lds, ctx->stream, p);
+            else if (ctx->fused_f32box) VC_KLAUNCH(VC_K_CARVE_ONE_LAUNCH, (k_carve_fused_hier<false, 1>), rgrid, block, lds, ctx->stream, p);
+            else VC_KLAUNCH(VC_K_CARVE_ONE_LAUNCH, (k_carve_fused_hier<false, 0>), rgrid, block, lds, ctx->stream, p);
         }
-        else if (ctx->ny % 64 == 0) hipLaunchKernelGGL((k_carve_fused<kSub, true>), grid, block, 0, ctx->stream, p);
-        else hipLaunchKernelGGL((k_carve_fused<kSub, false>), grid, block, 0, ctx->stream, p);
+        else if (ctx->ny % 64 == 0) VC_KLAUNCH(VC_K_CARVE_ONE_LAUNCH, (k_carve_fused<kSub, true>), grid, block, 0, ctx->stream, p);
+        else VC_KLAUNCH(VC_K_CARVE_ONE_LAUNCH, (k_carve_fused<kSub, false>), grid, block, 0, ctx->stream, p);
     } else {
         const dim3 grid(grid_for(n));
         if (mode == VC_MODE_LUT) {
-            if (want_vm) hipLaunchKernelGGL((k_carve_generic<true, true>), grid, block, 0, ctx->stream, p);
-            else hipLaunchKernelGGL((k_carve_generic<true, false>), grid, block, 0, ctx->stream, p);
+            if (want_vm) VC_KLAUNCH(VC_K_CARVE_ONE_LAUNCH, (k_carve_generic<true, true>), grid, block, 0, ctx->stream, p);
+            else VC_KLAUNCH(VC_K_CARVE_ONE_LAUNCH, (k_carve_generic<true, false>), grid, block, 0, ctx->stream, p);
         } else {
-            if (want_vm) hipLaunchKernelGGL((k_carve_generic<false, true>), grid, block, 0, ctx->stream, p);
-            else hipLaunchKernelGGL((k_carve_generic<false, false>), grid, block, 0, ctx->stream, p);
+            if (want_vm) VC_KLAUNCH(VC_K_CARVE_ONE_LAUNCH, (k_carve_generic<false, true>), grid, block, 0, ctx->stream, p);
+            else VC_KLAUNCH(VC_K_CARVE_ONE_LAUNCH, (k_carve_generic<false, false>), grid, block, 0, ctx->stream, p);
         }
     }
     VC_HIP(ctx, hipGetLastError());
@@ -1635,7 +1675,7 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     // kernels that do not know their group totals (fused, generic) get them counted
     const bool counted = fast && (mode == VC_MODE_LUT || (ctx->ny % 64 == 0 && ctx->fused_hier));
     if (!counted) {
-        hipLaunchKernelGGL(k_count_groups, dim3((ngroups + 3) / 4), block, 0, s2, sb.words.ptr, nwords, ngroups,
+        VC_KLAUNCH(VC_K_COUNT_GROUPS, k_count_groups, dim3((ngroups + 3) / 4), block, 0, s2, sb.words.ptr, nwords, ngroups,
                            sb.groupcnt.ptr);
         VC_HIP(ctx, hipGetLastError());
     }
@@ -1649,9 +1689,9 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
         VC_TRY(ensure(ctx, sb.busysum, kMaxScanBlocks));
         VC_TRY(ensure(ctx, sb.busyblock, 1));                    // the count of busy groups
     }
-    hipLaunchKernelGGL(k_scan_groups, dim3(nscan), dim3(kScanThreads), 0, s2, sb.groupcnt.ptr, ngroups, sb.groupoff.ptr,
-                       sb.blocksum.ptr, sb.blockoff.ptr, sb.h_total, sb.busy ? sb.busyoff.ptr : nullptr, sb.busysum.ptr,
-                       sb.busyblock.ptr, (uint32_t)ctx->dbg);
+    VC_KLAUNCH(VC_K_SCAN_GROUPS, k_scan_groups, dim3(nscan), dim3(kScanThreads), 0, s2, (const uint32_t *)sb.groupcnt.ptr, ngroups, sb.groupoff.ptr,
+               sb.blocksum.ptr, sb.blockoff.ptr, sb.h_total, sb.busy ? sb.busyoff.ptr : (uint32_t *)nullptr, sb.busysum.ptr,
+               sb.busyblock.ptr, (uint32_t)ctx->dbg);
     VC_HIP(ctx, hipGetLastError());
     // the two events a pipelined step hands from stream to stream ride on the launches in front of them where those are the
     // list-driven ones (large grids): {scan done} on k_finish_scan, {step done} on the expansion
@@ -1662,7 +1702,10 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     if (sb.busy) {
         // level 2 of both scans + the list in one launch (k_scan_groups has left the count in busyblock[0] when nscan == 1)
         scan_ridden = ride && want_scan_ev;
-        hipExtLaunchKernelGGL(k_finish_scan, dim3(grid_for(ngroups)), block, 0, s2, nullptr, scan_ridden ? sb.e_scan : nullptr, 0,
+        hipEvent_t fs0 = nullptr, fs1 = nullptr;
+        kev_pick(ctx, VC_K_FINISH_SCAN, fs0, fs1);
+        if (scan_ridden) { fs1 = sb.e_scan; if (fs0) sb.kused[VC_K_FINISH_SCAN][1] = fs1; }
+        hipExtLaunchKernelGGL(k_finish_scan, dim3(grid_for(ngroups)), block, 0, s2, fs0, fs1, 0,
                               (const uint64_t *)sb.blocksum.ptr, nscan, sb.blockoff.ptr, sb.h_total, (const uint32_t *)sb.busysum.ptr, sb.busyblock.ptr,
                               (const uint32_t *)sb.groupcnt.ptr, ngroups, (const uint32_t *)sb.busyoff.ptr, sb.busylist.ptr, (uint32_t)ctx->dbg);
         VC_HIP(ctx, hipGetLastError());
@@ -1699,6 +1742,7 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     e.capacity = sb.records.cap;
     e.busylist = sb.busylist.ptr; e.busycount = sb.busyblock.ptr;
     e.dbg = (uint32_t)ctx->dbg;
+    e.stats = p.stats;
     sb.emit_timed = false;
     bool scan_recorded = false;                                  // e_scan recorded by THIS step (Slot::carve_pending may still be set by an earlier one)
     if (want_scan_ev) {
@@ -1723,6 +1767,7 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     // then overwrite bits and grids under this step's carve).  Without e_scan, e2 is behind the carve kernels too.
     s.e_carve = scan_recorded ? sb.e_scan : sb.e2;
     s.carve_pending = true;
+    ctx->kev_sb = nullptr;
     sb.pending = true;
     sb.used = true;
     ctx->head = (ctx->head + 1) % kDepth;
@@ -1780,6 +1825,17 @@ int vc_carve_end(vc_ctx *ctx, uint64_t *n_out)
             ctx->tm.emit_ms_sum += ctx->tm.emit_ms;
             ctx->tm.emit_launches += 1;
         }
+        if (sb.emit_timed && sb.emit_ridden) { sb.kused[VC_K_EMIT][0] = sb.e_emit0; sb.kused[VC_K_EMIT][1] = sb.e2; sb.kmask |= 1u << VC_K_EMIT; }
+        for (int kk = 0; kk < VC_KERNEL_KINDS; ++kk) {
+            if (!((sb.kmask >> kk) & 1u)) continue;
+            if (kk <= VC_K_PREP_GRID) VC_HIP(ctx, hipEventSynchronize(sb.kused[kk][1]));   // (upload stream: not ordered before e2 by itself)
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, sb.kused[kk][0], sb.kused[kk][1]) == hipSuccess) {
+                ctx->tm.kernel_ms_sum[kk] += ms;
+                ctx->tm.kernel_launches[kk] += 1;
+            }
+        }
+        sb.kmask = 0;
         ctx->tm.prep_ms = 0;
         if (sb.prepped) ctx->tm.preps += 1;
         if (sb.prep_timed) {
@@ -1981,6 +2037,7 @@ int vc_set_option(vc_ctx *ctx, const char *name, int value)
     else if (k == "emit_lanes") ctx->emit_lanes = value != 0;
     else if (k == "overlap") ctx->overlap = value != 0;
     else if (k == "timing_detail") ctx->timing_detail = value != 0;
+    else if (k == "kernel_events") ctx->kernel_events = value != 0;
     else if (k == "launch_events") ctx->launch_events = value != 0;
     else if (k == "event_scope" && value >= 0 && value <= 2) {
         if (ctx->npending) return fail(ctx, VC_ERR_ARG, "carve steps are in flight: collect them with vc_carve_end first");
@@ -2056,6 +2113,14 @@ int vc_timing(vc_ctx *ctx, vc_timing_t *out)
         (void)hipEventElapsedTime(&ctx->tm.h2d_ms, ctx->ev_h[0], ctx->ev_h[1]);
         ctx->h2d_pending = false;
     }
+    memset(ctx->tm.work, 0, sizeof ctx->tm.work);
+    if (ctx->d_stats.ptr && ctx->npending == 0) {
+        std::vector<unsigned long long> h(ctx->d_stats.cap);
+        VC_HIP(ctx, hipSetDevice(ctx->device));
+        VC_HIP(ctx, hipMemcpy(h.data(), ctx->d_stats.ptr, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (int w = 0; w < VC_WORK_KINDS; ++w)
+            for (uint32_t k = 0; k < kShards; ++k) ctx->tm.work[w] += h[((size_t)w * kShards + k) * kStatStride];
+    }
     *out = ctx->tm;
     return VC_OK;
 }
@@ -2073,6 +2138,12 @@ int vc_timing_reset(vc_ctx *ctx)
     ctx->tm.preps_timed = 0;
     ctx->tm.emit_ms_sum = 0;
     ctx->tm.emit_launches = 0;
+    memset(ctx->tm.kernel_ms_sum, 0, sizeof ctx->tm.kernel_ms_sum);
+    memset(ctx->tm.kernel_launches, 0, sizeof ctx->tm.kernel_launches);
+    if (ctx->d_stats.ptr && ctx->npending == 0) {
+        VC_HIP(ctx, hipSetDevice(ctx->device));
+        VC_HIP(ctx, hipMemset(ctx->d_stats.ptr, 0, ctx->d_stats.cap * sizeof(unsigned long long)));
+    }
     return VC_OK;
 }
 

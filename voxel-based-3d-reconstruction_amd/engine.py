@@ -316,7 +316,11 @@ class CarveEngine:
         self._check(self._L.vc_timing(self._ctx, ctypes.byref(t)), "vc_timing")
         if reset:
             self._check(self._L.vc_timing_reset(self._ctx), "vc_timing_reset")
-        return {name: getattr(t, name) for name, _ in _lib.VcTiming._fields_}
+        out = {name: getattr(t, name) for name, _ in _lib.VcTiming._fields_ if name not in ("kernel_ms_sum", "kernel_launches", "work")}
+        out["kernels"] = {k: {"ms_sum": float(t.kernel_ms_sum[i]), "launches": int(t.kernel_launches[i])}
+                          for i, k in enumerate(_lib.KERNEL_KINDS) if t.kernel_launches[i]}
+        out["work"] = {k: int(t.work[i]) for i, k in enumerate(_lib.WORK_KINDS)}
+        return out
 
     # -- multi-GPU -------------------------------------------------------------------
     @staticmethod
