@@ -159,6 +159,7 @@ struct EmitParams {
     const uint32_t *busylist;   // k_emit_busy: the groups with survivors; busycount[0] of them
     const uint32_t *busycount;
     const uint64_t *entries;    // INDIRECT expansion: {bits, global index of bit 0} pairs instead of words
+    uint32_t entry_chunk;       // ... taken `entry_chunk` (16 or 64) per wave: see k_count_entries
     const uint32_t *groupcnt;   // survivors per group
     const uint32_t *groupoff;   // exclusive scan of groupcnt inside each scan block
     const uint64_t *blockoff;   // exclusive scan of the scan blocks' sums
@@ -1989,14 +1990,17 @@ __global__ __launch_bounds__(kBlock) void k_pack_busy(const uint64_t *__restrict
     }
 }
 
+// The gathered entries are expanded `chunk` entries per wave (EmitParams::entry_chunk), not 64: a wave that owns 64 dense words
+// writes ~2 800 records and keeps its slot for the whole launch -- one generation of long-lived waves that a higher-priority
+// stream's kernels cannot get past (the per-voxel level beside it went 41 -> 80 us); with 16 the slots turn over four times as often.
 __global__ __launch_bounds__(kBlock) void k_count_entries(const uint64_t *__restrict__ entries, uint64_t nent,
-                                                          uint32_t ngroups, uint32_t *__restrict__ groupcnt)
+                                                          uint32_t ngroups, uint32_t *__restrict__ groupcnt, uint32_t chunk)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t g = (blockIdx.x * kBlock + threadIdx.x) >> 6;
     if (g >= ngroups) return;
-    const uint64_t w = (uint64_t)g * kGroupWords + lane;
-    uint32_t cnt = (w < nent) ? (uint32_t)__popcll(entries[2 * w]) : 0u;
+    const uint64_t w = (uint64_t)g * chunk + lane;
+    uint32_t cnt = (lane < chunk && w < nent) ? (uint32_t)__popcll(entries[2 * w]) : 0u;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
     if (lane == 0) groupcnt[g] = cnt;
@@ -2396,10 +2400,10 @@ __device__ __forceinline__ EmitGroup emit_load_group(const EmitParams &p, uint32
     EmitGroup h;
     const uint64_t nwords = (p.n + 63) >> 6;
     h.out0 = p.blockoff[g / kScanBlock] + p.groupoff[g];
-    const uint64_t gw = (uint64_t)g * kGroupWords;
+    const uint64_t gw = (uint64_t)g * (INDIRECT ? p.entry_chunk : kGroupWords);
     h.mine = 0ull;
     h.mybase = 0;
-    if (gw + lane < nwords) {
+    if (gw + lane < nwords && (!INDIRECT || lane < p.entry_chunk)) {
         if (INDIRECT) {
             const ulonglong2 e = reinterpret_cast<const ulonglong2 *>(p.entries)[gw + lane];
             h.mine = e.x; h.mybase = (uint32_t)e.y;

@@ -189,6 +189,8 @@ struct vc_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // scan + record expansion of step i, beside the carve of step i+1 on `stream`
     hipStream_t stream_up = nullptr; // host-to-device copies of masks and images (overlap the carve in flight)
+    hipStream_t stream_x = nullptr;  // a rank of a communicator: packing + collectives of step i, beside the carve of step i + 1 (they waited in
+                                     // line on the carve stream: three launches, two collectives and their events, ~60 us per step)
     hipEvent_t ev_h[2] = {nullptr, nullptr};   // around the last mask upload (h2d_ms)
     bool h2d_pending = false;
     int overlap = 1;                 // (one stream when a communicator is attached: its collectives order everything)
@@ -357,7 +359,7 @@ void kev_pick(vc_ctx *ctx, int kind, hipEvent_t &start, hipEvent_t &stop)
 // (Re)creates the three streams for ctx->stream_priority / ctx->reserve_cus.  Nothing may be in flight.
 hipError_t make_streams(vc_ctx *ctx)
 {
-    hipStream_t *all[3] = {&ctx->stream, &ctx->stream2, &ctx->stream_up};
+    hipStream_t *all[4] = {&ctx->stream, &ctx->stream2, &ctx->stream_up, &ctx->stream_x};
     for (hipStream_t *st : all) {
         if (!*st) continue;
         hipError_t e = hipStreamSynchronize(*st);
@@ -388,7 +390,9 @@ hipError_t make_streams(vc_ctx *ctx)
     }
     e = prio ? hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, greatest) : hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) return e;
-    return prio ? hipStreamCreateWithPriority(&ctx->stream_up, hipStreamNonBlocking, greatest) : hipStreamCreateWithFlags(&ctx->stream_up, hipStreamNonBlocking);
+    e = prio ? hipStreamCreateWithPriority(&ctx->stream_up, hipStreamNonBlocking, greatest) : hipStreamCreateWithFlags(&ctx->stream_up, hipStreamNonBlocking);
+    if (e != hipSuccess) return e;
+    return prio ? hipStreamCreateWithPriority(&ctx->stream_x, hipStreamNonBlocking, greatest) : hipStreamCreateWithFlags(&ctx->stream_x, hipStreamNonBlocking);
 }
 
 // The events that only order one stream behind another ({scan done} of a step: carve stream -> expansion stream; a frame set's
@@ -849,13 +853,13 @@ int ensure_boxes(vc_ctx *ctx, bool tile)
 // Enqueues the packing of the current result's non-zero words into ctx->d_ent ({bits, base} pairs) and
 // {entries, survivors} into ctx->d_mine.  No host synchronisation; *h_xtotal holds the entry count
 // once the stream has drained.
-int enqueue_pack(vc_ctx *ctx, StepBuf &cur)
+int enqueue_pack(vc_ctx *ctx, StepBuf &cur, hipStream_t st)
 {
     const uint64_t n = cur.n;
     VC_TRY(ensure_exchange_scratch(ctx, 1));
     VC_TRY(ensure(ctx, cur.mine, 2));
     if (n == 0) {
-        VC_HIP(ctx, hipMemsetAsync(cur.mine.ptr, 0, 2 * sizeof(uint64_t), ctx->stream));
+        VC_HIP(ctx, hipMemsetAsync(cur.mine.ptr, 0, 2 * sizeof(uint64_t), st));
         *ctx->h_xtotal = 0;
         return VC_OK;
     }
@@ -869,32 +873,32 @@ int enqueue_pack(vc_ctx *ctx, StepBuf &cur)
     if (cur.nz_valid && cur.busy) {
         // the carve left the counts of non-zero words and the list of groups with survivors: no counting pass, and the packing
         // strides over the list (5 of 6 groups are empty; a launch over all of them is dispatch bound)
-        VC_TRY(scan_counts(ctx, ctx->stream, cur.groupnz.ptr, ngroups, ctx->d_xoff.ptr, ctx->d_xbsum.ptr, ctx->d_xboff.ptr, ctx->h_xtotal));
-        hipLaunchKernelGGL(k_pack_busy, dim3(1024), block, 0, ctx->stream, (const uint64_t *)cur.words.ptr, nwords, (const uint32_t *)cur.busylist.ptr,
+        VC_TRY(scan_counts(ctx, st, cur.groupnz.ptr, ngroups, ctx->d_xoff.ptr, ctx->d_xbsum.ptr, ctx->d_xboff.ptr, ctx->h_xtotal));
+        hipLaunchKernelGGL(k_pack_busy, dim3(1024), block, 0, st, (const uint64_t *)cur.words.ptr, nwords, (const uint32_t *)cur.busylist.ptr,
                            (const uint32_t *)cur.busyblock.ptr, (const uint32_t *)ctx->d_xoff.ptr, (const uint64_t *)ctx->d_xboff.ptr, nscan, ctx->i0(),
                            (const uint64_t *)(cur.blockoff.ptr + nscan), cur.ent.ptr, cur.mine.ptr);
         VC_HIP(ctx, hipGetLastError());
         return VC_OK;
     }
-    hipLaunchKernelGGL(k_count_nz, grid, block, 0, ctx->stream, cur.words.ptr, nwords, ngroups, cur.groupcnt.ptr,
+    hipLaunchKernelGGL(k_count_nz, grid, block, 0, st, cur.words.ptr, nwords, ngroups, cur.groupcnt.ptr,
                        ctx->d_xcnt.ptr);
     VC_HIP(ctx, hipGetLastError());
-    VC_TRY(scan_counts(ctx, ctx->stream, ctx->d_xcnt.ptr, ngroups, ctx->d_xoff.ptr, ctx->d_xbsum.ptr, ctx->d_xboff.ptr, ctx->h_xtotal));
-    hipLaunchKernelGGL(k_pack_entries, grid, block, 0, ctx->stream, cur.words.ptr, nwords, ngroups, cur.groupcnt.ptr, ctx->d_xoff.ptr,
+    VC_TRY(scan_counts(ctx, st, ctx->d_xcnt.ptr, ngroups, ctx->d_xoff.ptr, ctx->d_xbsum.ptr, ctx->d_xboff.ptr, ctx->h_xtotal));
+    hipLaunchKernelGGL(k_pack_entries, grid, block, 0, st, cur.words.ptr, nwords, ngroups, cur.groupcnt.ptr, ctx->d_xoff.ptr,
                        ctx->d_xboff.ptr, nscan, ctx->i0(), cur.blockoff.ptr + nscan, cur.ent.ptr, cur.mine.ptr);
     VC_HIP(ctx, hipGetLastError());
     return VC_OK;
 }
 
 // {entries, survivors} of every rank into cur.h_counts (valid once the stream has drained).
-int enqueue_counts_exchange(vc_ctx *ctx, StepBuf &cur)
+int enqueue_counts_exchange(vc_ctx *ctx, StepBuf &cur, hipStream_t st)
 {
     const int G = ctx->n_ranks;
     VC_TRY(ensure(ctx, cur.counts, (size_t)2 * G));
     if (!cur.h_counts)
         VC_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&cur.h_counts), sizeof(uint64_t) * 2 * VC_MAX_RANKS, hipHostMallocDefault));
-    VC_NCCL(ctx, g_rccl.AllGather(cur.mine.ptr, cur.counts.ptr, 2, ncclUint64, ctx->comm, ctx->stream));
-    VC_HIP(ctx, hipMemcpyAsync(cur.h_counts, cur.counts.ptr, sizeof(uint64_t) * 2 * G, hipMemcpyDeviceToHost, ctx->stream));
+    VC_NCCL(ctx, g_rccl.AllGather(cur.mine.ptr, cur.counts.ptr, 2, ncclUint64, ctx->comm, st));
+    VC_HIP(ctx, hipMemcpyAsync(cur.h_counts, cur.counts.ptr, sizeof(uint64_t) * 2 * G, hipMemcpyDeviceToHost, st));
     return VC_OK;
 }
 
@@ -952,7 +956,8 @@ int enqueue_expand(vc_ctx *ctx, hipStream_t st, const uint64_t *d_entries, uint6
     if (!h_total) h_total = ctx->h_xtotal + 1;                   // (page-locked word the scan leaves the survivor total in)
     *h_total = 0;
     if (M == 0) return VC_OK;
-    const uint32_t ngroups = (uint32_t)((M + kGroupWords - 1) / kGroupWords);
+    const uint32_t chunk = M <= (1ull << 24) ? 16u : kGroupWords;   // entries per wave (the scan takes 2^20 groups at most)
+    const uint32_t ngroups = (uint32_t)((M + chunk - 1) / chunk);
     VC_TRY(ensure_exchange_scratch(ctx, 1));
     VC_TRY(ensure(ctx, ctx->d_ycnt, ngroups));
     VC_TRY(ensure(ctx, ctx->d_yoff, ngroups));
@@ -964,7 +969,7 @@ int enqueue_expand(vc_ctx *ctx, hipStream_t st, const uint64_t *d_entries, uint6
         if (st != ctx->stream) VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     const dim3 grid((ngroups + 3) / 4), block(kBlock);
-    hipLaunchKernelGGL(k_count_entries, grid, block, 0, st, d_entries, M, ngroups, ctx->d_ycnt.ptr);
+    hipLaunchKernelGGL(k_count_entries, grid, block, 0, st, d_entries, M, ngroups, ctx->d_ycnt.ptr, chunk);
     VC_HIP(ctx, hipGetLastError());
     VC_TRY(scan_counts(ctx, st, ctx->d_ycnt.ptr, ngroups, ctx->d_yoff.ptr, ctx->d_ybsum.ptr, ctx->d_yboff.ptr, h_total));
     if (S_hint == 0) {
@@ -986,7 +991,7 @@ int enqueue_expand(vc_ctx *ctx, hipStream_t st, const uint64_t *d_entries, uint6
     }
     e.entries = d_entries;
     e.groupcnt = ctx->d_ycnt.ptr; e.groupoff = ctx->d_yoff.ptr; e.blockoff = ctx->d_yboff.ptr;
-    e.n = M * 64; e.i0 = 0; e.z0 = 0; e.ngroups = ngroups;
+    e.n = M * 64; e.i0 = 0; e.z0 = 0; e.ngroups = ngroups; e.entry_chunk = chunk;
     e.records = ctx->d_gathered.ptr; e.capacity = ctx->d_gathered.cap;
     e.lut = from_lut ? ctx->d_lut_color.ptr : nullptr;
     if (from_lut && cur.allseen) hipLaunchKernelGGL((k_emit_lanes<true, true, 8, true>), grid, block, 0, st, e);
@@ -1064,6 +1069,7 @@ int vc_destroy(vc_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     if (ctx->stream_up) (void)hipStreamSynchronize(ctx->stream_up);
+    if (ctx->stream_x) (void)hipStreamSynchronize(ctx->stream_x);
     if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
     for (Slot &s : ctx->slots) {
         release_slot(s);
@@ -1105,6 +1111,7 @@ int vc_destroy(vc_ctx *ctx)
     for (int i = 0; i < 4; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream_up) (void)hipStreamDestroy(ctx->stream_up);
+    if (ctx->stream_x) (void)hipStreamDestroy(ctx->stream_x);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return VC_OK;
@@ -1118,6 +1125,7 @@ int vc_synchronize(vc_ctx *ctx)
     VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     VC_HIP(ctx, hipStreamSynchronize(ctx->stream2));
     VC_HIP(ctx, hipStreamSynchronize(ctx->stream_up));
+    VC_HIP(ctx, hipStreamSynchronize(ctx->stream_x));
     return finish_gather(ctx);
 }
 
@@ -1480,11 +1488,13 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     // vc_allgather finds them on the host and only has the payload and the expansion left
     sb.counts_exchanged = false;
     const bool auto_exchange = sb.no_records && ctx->comm && ctx->gather_compact;
+    // packing + collectives of a step run on the exchange stream, beside the next step's carve
+    hipStream_t sx = ctx->overlap ? ctx->stream_x : ctx->stream;
     if (n == 0) {
         if (auto_exchange) {                     // an empty slab still takes part in the collective
-            VC_TRY(enqueue_pack(ctx, sb));
-            VC_TRY(enqueue_counts_exchange(ctx, sb));
-            VC_HIP(ctx, hipEventRecord(sb.e2, ctx->stream));
+            VC_TRY(enqueue_pack(ctx, sb, sx));
+            VC_TRY(enqueue_counts_exchange(ctx, sb, sx));
+            VC_HIP(ctx, hipEventRecord(sb.e2, sx));
             sb.counts_exchanged = true;
         }
         sb.pending = true; sb.used = false; ctx->head = (ctx->head + 1) % kDepth; ctx->npending++;
@@ -1695,13 +1705,14 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     VC_HIP(ctx, hipGetLastError());
     // the two events a pipelined step hands from stream to stream ride on the launches in front of them where those are the
     // list-driven ones (large grids): {scan done} on k_finish_scan, {step done} on the expansion
-    const bool want_scan_ev = !sb.no_records && (s3 != ctx->stream || sb.carve_timed);
+    const bool xstream = auto_exchange && sx != ctx->stream;     // the packing waits for the scan across streams
+    const bool want_scan_ev = (!sb.no_records && (s3 != ctx->stream || sb.carve_timed)) || xstream;
     const bool ride = ctx->launch_events && !sb.no_records;
     sb.emit_ridden = ride;
     bool scan_ridden = false;
     if (sb.busy) {
         // level 2 of both scans + the list in one launch (k_scan_groups has left the count in busyblock[0] when nscan == 1)
-        scan_ridden = ride && want_scan_ev;
+        scan_ridden = ctx->launch_events && want_scan_ev;
         hipEvent_t fs0 = nullptr, fs1 = nullptr;
         kev_pick(ctx, VC_K_FINISH_SCAN, fs0, fs1);
         if (scan_ridden) { fs1 = sb.e_scan; if (fs0) sb.kused[VC_K_FINISH_SCAN][1] = fs1; }
@@ -1747,8 +1758,9 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     bool scan_recorded = false;                                  // e_scan recorded by THIS step (Slot::carve_pending may still be set by an earlier one)
     if (want_scan_ev) {
         if (!scan_ridden) VC_HIP(ctx, hipEventRecord(sb.e_scan, ctx->stream));     // cross-stream dependency
-        if (s3 != ctx->stream) VC_HIP(ctx, hipStreamWaitEvent(s3, sb.e_scan, 0));
-        sb.emit_timed = true;
+        if (!sb.no_records && s3 != ctx->stream) VC_HIP(ctx, hipStreamWaitEvent(s3, sb.e_scan, 0));
+        if (xstream) VC_HIP(ctx, hipStreamWaitEvent(sx, sb.e_scan, 0));
+        sb.emit_timed = !sb.no_records;
         scan_recorded = true;
     }
     if (!sb.no_records) {
@@ -1756,11 +1768,11 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
         if (ride) sb.emit_timed = true;
     }
     if (auto_exchange) {
-        VC_TRY(enqueue_pack(ctx, sb));
-        VC_TRY(enqueue_counts_exchange(ctx, sb));
+        VC_TRY(enqueue_pack(ctx, sb, sx));
+        VC_TRY(enqueue_counts_exchange(ctx, sb, sx));
         sb.counts_exchanged = true;
     }
-    if (!ride || auto_exchange) VC_HIP(ctx, hipEventRecord(sb.e2, sb.no_records ? s2 : s3));
+    if (!ride || auto_exchange) VC_HIP(ctx, hipEventRecord(sb.e2, auto_exchange ? sx : sb.no_records ? s2 : s3));
     if (!sb.no_records && s3 != ctx->stream) { s.e_emit = sb.e2; s.emit_pending = true; }   // the expansion reads the slot's bits / images
     // the slot's next preparation waits for the kernels of THIS step that read its bits / grids: always this step's own event
     // (a flag left set by an earlier step on the same slot must not keep that step's event in place: the preparation would
@@ -2187,6 +2199,7 @@ int vc_comm_destroy(vc_ctx *ctx)
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipStreamSynchronize(ctx->stream2);
+        (void)hipStreamSynchronize(ctx->stream_x);
         ctx->gpend[0] = ctx->gpend[1] = false;
         VC_NCCL(ctx, g_rccl.CommDestroy(ctx->comm));
         ctx->comm = nullptr;
@@ -2201,7 +2214,7 @@ int vc_pack_entries(vc_ctx *ctx, uint64_t *n_entries_out)
     if (!ctx || !n_entries_out) return VC_ERR_ARG;
     if (!ctx->carved) return fail(ctx, VC_ERR_ARG, "no carve result to pack");
     VC_HIP(ctx, hipSetDevice(ctx->device));
-    VC_TRY(enqueue_pack(ctx, ctx->sb[ctx->cur]));
+    VC_TRY(enqueue_pack(ctx, ctx->sb[ctx->cur], ctx->stream));
     VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->packed_entries = *ctx->h_xtotal;
     ctx->packed = true;
@@ -2246,17 +2259,18 @@ static int allgather_compact(vc_ctx *ctx, uint64_t *counts_out, uint64_t *total_
 {
     const int G = ctx->n_ranks;
     StepBuf &cur = ctx->sb[ctx->cur];
+    hipStream_t sx = ctx->overlap ? ctx->stream_x : ctx->stream;    // every collective of the compact form is queued here
     const uint32_t half = ctx->gseq & 1u;
     VC_TRY(finish_one(ctx, half));                               // the gather before last owned this half; the last one may still run
     DevBuf<uint64_t> &ent_all = ctx->d_ent_all[half];
     hipEvent_t *E = ctx->gx[ctx->gx_next];                       // this gather's own events: see vc_ctx::gx
     ctx->gx_idx[half] = ctx->gx_next;
     ctx->gx_next = (ctx->gx_next + 1) % kGatherRing;
-    VC_HIP(ctx, hipEventRecord(E[0], ctx->stream));
+    VC_HIP(ctx, hipEventRecord(E[0], sx));
     if (!cur.counts_exchanged) {                 // vc_carve_begin did not do it (records were kept)
-        VC_TRY(enqueue_pack(ctx, cur));
-        VC_TRY(enqueue_counts_exchange(ctx, cur));
-        VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        VC_TRY(enqueue_pack(ctx, cur, sx));
+        VC_TRY(enqueue_counts_exchange(ctx, cur, sx));
+        VC_HIP(ctx, hipStreamSynchronize(sx));
     }
     uint64_t M = 0, S = 0;
     for (int r = 0; r < G; ++r) { M += cur.h_counts[2 * r]; S += cur.h_counts[2 * r + 1]; }
@@ -2268,7 +2282,7 @@ static int allgather_compact(vc_ctx *ctx, uint64_t *counts_out, uint64_t *total_
         const uint64_t cnt = cur.h_counts[2 * r];
         if (cnt) {
             ncclResult_t rc = g_rccl.Broadcast(cur.ent.ptr, ent_all.ptr + 2 * disp, 2 * cnt, ncclUint64, r,
-                                               ctx->comm, ctx->stream);
+                                               ctx->comm, sx);
             if (rc != ncclSuccess) {
                 g_rccl.GroupEnd();
                 return fail(ctx, VC_ERR_RCCL, "ncclBroadcast(root %d): %s", r, g_rccl.GetErrorString(rc));
@@ -2277,13 +2291,13 @@ static int allgather_compact(vc_ctx *ctx, uint64_t *counts_out, uint64_t *total_
         disp += cnt;
     }
     VC_NCCL(ctx, g_rccl.GroupEnd());
-    VC_HIP(ctx, hipEventRecord(E[2], ctx->stream));
+    VC_HIP(ctx, hipEventRecord(E[2], sx));
     // the expansion runs beside the next step's carve (second stream) when the call does not wait for it anyway
-    hipStream_t xs = (ctx->overlap && !ctx->gather_sync) ? ctx->stream2 : ctx->stream;
-    if (xs != ctx->stream) VC_HIP(ctx, hipStreamWaitEvent(xs, E[2], 0));
+    hipStream_t xs = (ctx->overlap && !ctx->gather_sync) ? ctx->stream2 : sx;
+    if (xs != sx) VC_HIP(ctx, hipStreamWaitEvent(xs, E[2], 0));
     if (S) VC_TRY(enqueue_expand(ctx, xs, ent_all.ptr, M, S, ctx->h_xtotal + 2 + half));
     VC_HIP(ctx, hipEventRecord(E[1], xs));
-    if (S && cur.color_cam >= 0 && xs != ctx->stream) {          // the expansion reads the slot's bits / images beside the carve stream
+    if (S && cur.color_cam >= 0) {          // the expansion reads the slot's bits / images beside the carve stream
         Slot &sl = ctx->slots[cur.slot];
         sl.e_emit = E[1];
         sl.emit_pending = true;
