@@ -195,6 +195,17 @@ int vc_fetch_viewmask(vc_ctx *ctx, uint16_t *viewmask);
  * slab-local voxel j (consumer shape of assignment.py:143-146). */
 int vc_fetch_occupancy(vc_ctx *ctx, uint8_t *bits);
 
+/* ---- the step before the path, its data-parallel part ------------------------------------------------------
+ * Front half of extract_foreground_mask, background_subtraction.py:153-168.  Host buffers in and out (the stateful background
+ * model, bg_model.apply :158, and findContours / fill :171-193 sit between these calls and stay with cv2 on the CPU).
+ * vc_bgr_to_hsv: replaces cv2.cvtColor(image, cv2.COLOR_BGR2HSV) (:155) on uint8 [H,W,3] -- OpenCV's 8-bit fixed-point
+ * conversion (H in 0..179).  vc_mask_morphology: replaces cv2.morphologyEx(mask, MORPH_OPEN / MORPH_CLOSE,
+ * getStructuringElement(MORPH_RECT, (ksize, ksize))) on uint8 [H,W], opening first when both flags are set: ksize 3 = the
+ * pre-filter (:161-168), ksize 2 = the post-filter (:195-203; the carve path applies that one itself on upload, see
+ * vc_set_mask_postfilter).  Parity with cv2 is unpinned (oracle/foreground_np.py restates OpenCV's published code). */
+int vc_bgr_to_hsv(vc_ctx *ctx, const uint8_t *bgr, uint32_t H, uint32_t W, uint8_t *hsv);
+int vc_mask_morphology(vc_ctx *ctx, const uint8_t *mask, uint32_t H, uint32_t W, uint32_t ksize, int open, int close, uint8_t *out);
+
 /* ---- the step after the path: marching cubes over the dense ON/OFF volume -------------------------------
  * Replaces skimage.measure.marching_cubes(voxels_status, 0) of plot_marching_cubes, voxel_reconstruction.py:127-163, whose
  * input the reference builds as the statuses in voxel order reshaped to (width, height*2, depth) (assignment.py:143-146).

@@ -391,6 +391,44 @@ def test_device_mask_postfilter_matches_restatement(eng, cams, masks):
         assert np.array_equal(eng.fetch_mask(c), np.where(noisy[c] > 0, 255, 0))
 
 
+def test_foreground_front_half_on_device(eng, frames):
+    """SURVEY 8(f)-2, the data-parallel part of the step before the path (background_subtraction.py:153-168): BGR -> HSV in OpenCV's
+    8-bit convention for ALL 2^24 colours, the 3x3 (pre) and 2x2 (post) open / close, and the drop-in extract_foreground_mask with
+    stand-ins for its two cv2 stages -- each equal to the numpy restatement (parity with cv2 itself: unpinned)."""
+    from oracle import foreground_np as fg, postfilter_np as pf
+    from voxcarve import background_subtraction as bs
+    every = np.arange(1 << 24, dtype=np.uint32)
+    cube = np.stack([every & 255, (every >> 8) & 255, every >> 16], axis=-1).astype(np.uint8).reshape(4096, 4096, 3)
+    assert np.array_equal(eng.bgr_to_hsv(cube), fg.bgr_to_hsv(cube))
+    assert np.array_equal(eng.bgr_to_hsv(frames[0]), fg.bgr_to_hsv(frames[0]))
+    rng = np.random.default_rng(9)
+    for shape in ((486, 644), (1, 1), (3, 2), (37, 129)):
+        m = (rng.integers(0, 256, shape, dtype=np.uint8) * (rng.random(shape) < 0.6)).astype(np.uint8)
+        for op, cl in ((False, False), (True, False), (False, True), (True, True)):
+            assert np.array_equal(eng.mask_morphology(m, 3, op, cl), fg.pre_filter(m, op, cl)), (shape, op, cl)
+            want2 = m
+            if op:
+                want2 = pf.dilate2x2(pf.erode2x2(want2))
+            if cl:
+                want2 = pf.erode2x2(pf.dilate2x2(want2))
+            assert np.array_equal(eng.mask_morphology(m, 2, op, cl), want2), (shape, op, cl)
+
+    class Model:                                              # stands in for a cv2 background model: apply(image, None, learning_rate)
+        def apply(self, hsv, _, lr):
+            assert lr == 0
+            return np.where((hsv[..., 2] > 128) & (hsv[..., 1] > 40), 255, np.where(hsv[..., 0] > 170, 127, 0)).astype(np.uint8)
+
+    keep = lambda mask, a, b: np.where(mask == 255, 255, 0).astype(np.uint8)          # stands in for the contour stage
+    img = frames[2]
+    for flags in ((False, False, True, True), (False, True, True, True), (True, True, False, False), (False, False, False, True)):
+        got = bs.extract_foreground_mask(img, Model(), 0, 5000, 115, *flags, engine=eng, contour_stage=keep)
+        want = pf.post_filter(keep(fg.pre_filter(Model().apply(fg.bgr_to_hsv(img), None, 0), flags[0], flags[1]), 0, 0), flags[2], flags[3])
+        assert np.array_equal(got, want), flags
+    from voxcarve._lib import VoxcarveError
+    with pytest.raises(VoxcarveError, match="cv2"):           # the real contour stage needs cv2: absent here, and says so
+        bs.extract_foreground_mask(img, Model(), engine=eng)
+
+
 def test_cropped_block_grid_edge_cases(eng, cams, masks, frames):
     """The block grids keep only the blocks around each camera's foreground (word-aligned columns, block rows):
     foreground confined to a corner pixel, the last row / column, one pixel wide lines, two far-apart blobs,

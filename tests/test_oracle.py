@@ -227,3 +227,32 @@ def test_marching_cubes_table_is_the_derived_one_and_sound():
     rng = np.random.default_rng(0)
     noise = np.pad(rng.random((7, 8, 9)) < 0.5, 1)
     assert mc.mesh_invariants(*mc.extract(noise, 0.5))[:2] == (True, True)
+
+
+def test_foreground_restatement_hsv_and_3x3_morphology():
+    """oracle/foreground_np.py (parity with cv2 unpinned): the 8-bit HSV conversion against the textbook definition -- OpenCV's
+    fixed-point result is within one count of the rounded real-valued H / 2, S, V on every one of 20 000 random colours and on
+    the primaries exactly -- and the 3x3 erosion / dilation against a plain window loop."""
+    import colorsys
+    from oracle import foreground_np as fg
+    prim = np.array([[0, 0, 255], [0, 255, 0], [255, 0, 0], [0, 255, 255], [255, 255, 0], [255, 0, 255], [0, 0, 0], [255, 255, 255],
+                     [128, 128, 128]], np.uint8)                      # BGR: red, green, blue, yellow, cyan, magenta, black, white, grey
+    want = [[0, 255, 255], [60, 255, 255], [120, 255, 255], [30, 255, 255], [90, 255, 255], [150, 255, 255], [0, 0, 0], [0, 0, 255], [0, 0, 128]]
+    assert fg.bgr_to_hsv(prim).tolist() == want
+    rng = np.random.default_rng(3)
+    cols = rng.integers(0, 256, (20000, 3), dtype=np.uint8)
+    got = fg.bgr_to_hsv(cols).astype(int)
+    for (b, g, r), (h, s, v) in zip(cols.tolist()[:4000], got.tolist()[:4000]):
+        hh, ss, vv = colorsys.rgb_to_hsv(r / 255.0, g / 255.0, b / 255.0)
+        assert v == max(b, g, r) and abs(s - ss * 255.0) <= 1.0
+        dh = abs(h - hh * 180.0)
+        assert min(dh, 180.0 - dh) <= 1.0 or s == 0
+    assert got[:, 0].max() < 180
+    img = rng.integers(0, 256, (13, 17), dtype=np.uint8)
+    ero, dil = fg.erode3x3(img), fg.dilate3x3(img)
+    for y in range(13):
+        for x in range(17):
+            win = img[max(0, y - 1):y + 2, max(0, x - 1):x + 2]
+            assert ero[y, x] == win.min() and dil[y, x] == win.max()
+    assert np.array_equal(fg.pre_filter(img), img)
+    assert np.array_equal(fg.pre_filter(img, True, True), fg.erode3x3(fg.dilate3x3(fg.dilate3x3(fg.erode3x3(img)))))

@@ -66,6 +66,8 @@ SIGNATURES = {
     "vc_touch_masks": (ctypes.c_int, [c_ctx, ctypes.c_uint32]),
     "vc_set_mask_postfilter": (ctypes.c_int, [c_ctx, c_u8p, c_u8p]),
     "vc_fetch_mask": (ctypes.c_int, [c_ctx, ctypes.c_uint32, ctypes.c_uint32, c_u8p]),
+    "vc_bgr_to_hsv": (ctypes.c_int, [c_ctx, c_u8p, ctypes.c_uint32, ctypes.c_uint32, c_u8p]),
+    "vc_mask_morphology": (ctypes.c_int, [c_ctx, c_u8p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, c_u8p]),
     "vc_upload_frame": (ctypes.c_int, [c_ctx, ctypes.c_uint32, ctypes.c_uint32, c_u8p]),
     "vc_build_lut": (ctypes.c_int, [c_ctx]),
     "vc_fetch_lut": (ctypes.c_int, [c_ctx, ctypes.c_uint32, c_i32p]),

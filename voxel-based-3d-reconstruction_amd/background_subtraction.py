@@ -1,0 +1,70 @@
+"""The reference's ``extract_foreground_mask`` (background_subtraction.py:129-208) with its data-parallel stages on the GPU.
+
+SURVEY 8(f)-2, the step BEFORE the carve path.  Same name, parameters and defaults as the reference's function.  What runs where:
+
+  BGR -> HSV (:155)                      GPU   CarveEngine.bgr_to_hsv          (OpenCV's 8-bit fixed-point conversion)
+  bg_model.apply (:158)                  CPU   the caller's cv2 background model: a stateful mixture model, frame after frame
+  3x3 open / close before the contours   GPU   CarveEngine.mask_morphology(.., 3, ..)
+  contours: fill the figures, re-open
+  their large holes (:171-193)           CPU   cv2.findContours / fillPoly / drawContours: sequential border following
+  2x2 open / close after them (:195-203) GPU   CarveEngine.mask_morphology(.., 2, ..)
+  final threshold (:206)                 host  one comparison
+
+The two CPU stages need cv2 (opencv-contrib, as the reference does); without it the call fails by name -- there is no
+substitute for them in this package.  Parity of the GPU stages with cv2 is unpinned (see oracle/foreground_np.py)."""
+import numpy as np
+
+from ._lib import VoxcarveError
+
+_engine = None
+
+
+def _default_engine():
+    global _engine
+    if _engine is None:
+        from .engine import CarveEngine
+        _engine = CarveEngine(0)
+    return _engine
+
+
+def fill_figures(mask, figure_threshold, figure_inner_threshold):
+    """The contour stage (:171-193) with cv2: every contour of the RETR_TREE hierarchy whose area reaches ``figure_threshold``
+    is drawn filled; each of its direct children whose oriented area reaches ``figure_inner_threshold`` is cleared again and
+    its outline kept."""
+    try:
+        import cv2
+    except ImportError as exc:
+        raise VoxcarveError("extract_foreground_mask: the contour stage (findContours / fillPoly, background_subtraction.py:171-193) "
+                            "runs on cv2, which is not importable here (%s)" % exc)
+    contours, hierarchy = cv2.findContours(mask, cv2.RETR_TREE, cv2.CHAIN_APPROX_SIMPLE)
+    out = np.zeros(mask.shape, dtype=np.uint8)
+    for k, outer in enumerate(contours):
+        if cv2.contourArea(outer) < figure_threshold:
+            continue
+        cv2.drawContours(out, [outer], -1, 255)
+        cv2.fillPoly(out, [outer], 255)
+        child = hierarchy[0][k][2]                            # first child; siblings follow through field 0
+        while child != -1:
+            hole = contours[child]
+            if cv2.contourArea(hole, True) >= figure_inner_threshold:
+                cv2.fillPoly(out, [hole], 0)
+                cv2.drawContours(out, [hole], -1, 255)
+            child = hierarchy[0][child][0]
+    return out
+
+
+def extract_foreground_mask(image, bg_model, learning_rate=0, figure_threshold=5000, figure_inner_threshold=115,
+                            apply_opening_pre=False, apply_closing_pre=False, apply_opening_post=False,
+                            apply_closing_post=False, engine=None, contour_stage=None):
+    """Foreground mask (uint8 {0, 255} [H, W]) of a BGR image; reference background_subtraction.py:129-208, same parameters.
+    ``engine``: the CarveEngine whose device does the work (default: one on device 0); ``contour_stage``: what stands in for
+    ``fill_figures`` (tests; default: the cv2 one)."""
+    eng = engine if engine is not None else _default_engine()
+    hsv = eng.bgr_to_hsv(image)
+    model_mask = np.ascontiguousarray(bg_model.apply(hsv, None, learning_rate), dtype=np.uint8)
+    if apply_opening_pre or apply_closing_pre:
+        model_mask = eng.mask_morphology(model_mask, 3, apply_opening_pre, apply_closing_pre)
+    figures = (contour_stage or fill_figures)(model_mask, figure_threshold, figure_inner_threshold)
+    if apply_opening_post or apply_closing_post:
+        figures = eng.mask_morphology(figures, 2, apply_opening_post, apply_closing_post)
+    return np.where(figures > 0, 255, 0).astype(np.uint8)

@@ -32,6 +32,7 @@
 #include "../../include/voxcarve.h"
 #include "vc_kernels.h"
 #include "vc_mc.h"
+#include "vc_fg.h"
 
 #pragma clang fp contract(off)
 
@@ -325,6 +326,8 @@ struct vc_ctx {
     DevBuf<int32_t> d_lut_color;             // colour camera's table over the WHOLE grid (expansion of remote words)
     int lut_color_cam = -1;
 
+    DevBuf<uint8_t> d_fg;            // vc_bgr_to_hsv / vc_mask_morphology: input | output | scratch images
+    DevBuf<int32_t> d_hsvdiv;        // OpenCV's two division tables of the 8-bit HSV conversion (sdiv | hdiv)
     vc_timing_t tm;
     StepBuf *kev_sb = nullptr;       // timing_detail: the step whose kernels are being queued (their launches carry its per-kind events)
     DevBuf<unsigned long long> d_stats;   // timing_detail: the kernels' work counters, [VC_WORK_KINDS][kShards][kStatStride]
@@ -1099,7 +1102,7 @@ int vc_destroy(vc_ctx *ctx)
         for (int kk = 0; kk < VC_KERNEL_KINDS; ++kk)
             for (int i = 0; i < 2; ++i) if (b.kev[kk][i]) (void)hipEventDestroy(b.kev[kk][i]);
     }
-    release(ctx->d_stats);
+    release(ctx->d_stats); release(ctx->d_fg); release(ctx->d_hsvdiv);
     release(ctx->d_viewmask); release(ctx->d_scratch); release(ctx->d_counts); release(ctx->d_gathered);
     release(ctx->d_ent_all[0]); release(ctx->d_ent_all[1]); release(ctx->d_xcnt); release(ctx->d_xoff); release(ctx->d_xbsum);
     release(ctx->d_xboff); release(ctx->d_lut_color);
@@ -1564,6 +1567,11 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
     p.bbox = ctx->d_bbox.ptr;
     const size_t grid_lds = ((size_t)s.budget_words + 8) * sizeof(uint32_t);
 
+    // VC_MODE_FUSED colours the survivors from the colour camera's table over the whole grid: projected once, HERE -- in front of
+    // the carve kernels on their stream, so that {scan done}, which the expansion waits for on its own stream and which rides
+    // on the k_finish_scan launch, is behind it (queued where the expansion's parameters are set up it would follow that
+    // launch, and the first expansion would read a table still being written)
+    if (mode == VC_MODE_FUSED && ctx->fused_color_table && color_cam >= 0 && !sb.no_records) VC_TRY(ensure_color_table(ctx, color_cam));
     if (sb.carve_timed) VC_HIP(ctx, hipEventRecord(sb.e0, ctx->stream));
     const dim3 block(kBlock);
     if (fast) {
@@ -1744,8 +1752,8 @@ int vc_carve_begin(vc_ctx *ctx, uint32_t slot, uint32_t min_views, int color_cam
         else if (mode == VC_MODE_LUT) e.lut = ctx->d_lut.ptr + (size_t)color_cam * p.n_pad;
         else if (ctx->fused_color_table && !sb.no_records) {
             // table-free carve, but the colour look-up of the survivors reads the colour camera's table (4 B per
-            // voxel of the whole grid, one camera) instead of projecting every survivor again
-            VC_TRY(ensure_color_table(ctx, color_cam));
+            // voxel of the whole grid, one camera: made in front of this step's carve kernels, see above) instead of
+            // projecting every survivor again
             e.lut = ctx->d_lut_color.ptr + ctx->i0();
         }
     }
@@ -2035,6 +2043,66 @@ int vc_fetch_mesh(vc_ctx *ctx, float *verts, uint32_t *faces)
     VC_HIP(ctx, hipSetDevice(ctx->device));
     if (verts && ctx->mc_verts) VC_HIP(ctx, hipMemcpy(verts, ctx->d_mcverts.ptr, ctx->mc_verts * 3 * sizeof(float), hipMemcpyDeviceToHost));
     if (faces && ctx->mc_faces) VC_HIP(ctx, hipMemcpy(faces, ctx->d_mcfaces.ptr, ctx->mc_faces * 3 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return VC_OK;
+}
+
+// ---- the step before the path, its data-parallel part (reference background_subtraction.py:153-168) ----
+int vc_bgr_to_hsv(vc_ctx *ctx, const uint8_t *bgr, uint32_t H, uint32_t W, uint8_t *hsv)
+{
+    if (!ctx || !bgr || !hsv) return VC_ERR_ARG;
+    if (H == 0 || W == 0 || (uint64_t)H * W > 0x3fffffffull) return fail(ctx, VC_ERR_ARG, "image size %u x %u", H, W);
+    VC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t npix = (size_t)H * W;
+    hipStream_t st = ctx->stream_up;
+    if (!ctx->d_hsvdiv.ptr) {
+        // as OpenCV builds them (color_hsv: RGB2HSV_b): saturate_cast<int>(double) = round half to even
+        int32_t t[512];
+        t[0] = t[256] = 0;
+        for (int i = 1; i < 256; ++i) {
+            t[i] = (int32_t)std::nearbyint((double)(255 << kHsvShift) / (1.0 * i));
+            t[256 + i] = (int32_t)std::nearbyint((double)(180 << kHsvShift) / (6.0 * i));
+        }
+        VC_TRY(ensure(ctx, ctx->d_hsvdiv, 512));
+        VC_HIP(ctx, hipMemcpy(ctx->d_hsvdiv.ptr, t, sizeof t, hipMemcpyHostToDevice));
+    }
+    VC_TRY(ensure(ctx, ctx->d_fg, npix * 6 + 64));
+    uint8_t *d_in = ctx->d_fg.ptr, *d_out = d_in + npix * 3;
+    VC_HIP(ctx, hipMemcpyAsync(d_in, bgr, npix * 3, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_bgr2hsv, dim3((uint32_t)((npix + 255) / 256)), dim3(256), 0, st, (const uint8_t *)d_in, d_out, (uint32_t)npix,
+                       (const int32_t *)ctx->d_hsvdiv.ptr, (const int32_t *)(ctx->d_hsvdiv.ptr + 256));
+    VC_HIP(ctx, hipGetLastError());
+    VC_HIP(ctx, hipMemcpyAsync(hsv, d_out, npix * 3, hipMemcpyDeviceToHost, st));
+    VC_HIP(ctx, hipStreamSynchronize(st));
+    return VC_OK;
+}
+
+int vc_mask_morphology(vc_ctx *ctx, const uint8_t *mask, uint32_t H, uint32_t W, uint32_t ksize, int open, int close, uint8_t *out)
+{
+    if (!ctx || !mask || !out) return VC_ERR_ARG;
+    if (ksize != 2 && ksize != 3) return fail(ctx, VC_ERR_ARG, "structuring element %u x %u: the reference uses 3 x 3 (pre) and 2 x 2 (post)", ksize, ksize);
+    if (H == 0 || W == 0 || (uint64_t)H * W > 0xffffffffull) return fail(ctx, VC_ERR_ARG, "image size %u x %u", H, W);
+    VC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t npix = (size_t)H * W;
+    hipStream_t st = ctx->stream_up;
+    VC_TRY(ensure(ctx, ctx->d_fg, npix * 6 + 64));
+    uint8_t *a = ctx->d_fg.ptr, *b = a + npix;
+    VC_HIP(ctx, hipMemcpyAsync(a, mask, npix, hipMemcpyHostToDevice, st));
+    const dim3 g((uint32_t)((npix + 255) / 256)), blk(256);
+    auto pass = [&](bool dilate) {                               // a -> b, then the two swap
+        if (ksize == 3) {
+            if (dilate) hipLaunchKernelGGL(k_morph3x3<true>, g, blk, 0, st, (const uint8_t *)a, b, H, W);
+            else hipLaunchKernelGGL(k_morph3x3<false>, g, blk, 0, st, (const uint8_t *)a, b, H, W);
+        } else {
+            if (dilate) hipLaunchKernelGGL(k_morph2x2<true>, g, blk, 0, st, (const uint8_t *)a, b, H, W);
+            else hipLaunchKernelGGL(k_morph2x2<false>, g, blk, 0, st, (const uint8_t *)a, b, H, W);
+        }
+        uint8_t *t = a; a = b; b = t;
+    };
+    if (open) { pass(false); pass(true); }                       // MORPH_OPEN = erode, dilate
+    if (close) { pass(true); pass(false); }                      // MORPH_CLOSE = dilate, erode (opening first when both are asked)
+    VC_HIP(ctx, hipGetLastError());
+    VC_HIP(ctx, hipMemcpyAsync(out, a, npix, hipMemcpyDeviceToHost, st));
+    VC_HIP(ctx, hipStreamSynchronize(st));
     return VC_OK;
 }
 

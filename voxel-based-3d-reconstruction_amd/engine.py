@@ -126,6 +126,27 @@ class CarveEngine:
         self._check(self._L.vc_set_mask_postfilter(self._ctx, _ptr(o, ctypes.c_uint8) if o is not None else None,
                                                    _ptr(c, ctypes.c_uint8) if c is not None else None), "vc_set_mask_postfilter")
 
+    # -- the step before the path: data-parallel part of extract_foreground_mask --------------------------------
+    def bgr_to_hsv(self, image):
+        """cv2.cvtColor(image, cv2.COLOR_BGR2HSV) on uint8 [H,W,3], on the device (background_subtraction.py:155)."""
+        a = np.ascontiguousarray(image, dtype=np.uint8)
+        if a.ndim != 3 or a.shape[2] != 3:
+            raise ValueError("image shape %s, expected [H, W, 3]" % (a.shape,))
+        out = np.empty_like(a)
+        self._check(self._L.vc_bgr_to_hsv(self._ctx, _ptr(a, ctypes.c_uint8), a.shape[0], a.shape[1], _ptr(out, ctypes.c_uint8)), "vc_bgr_to_hsv")
+        return out
+
+    def mask_morphology(self, mask, ksize, opening=False, closing=False):
+        """cv2.morphologyEx with a ksize x ksize MORPH_RECT element on uint8 [H,W]: MORPH_OPEN, then MORPH_CLOSE, as asked
+        (background_subtraction.py:161-168 with ksize 3, :195-203 with ksize 2)."""
+        a = np.ascontiguousarray(mask, dtype=np.uint8)
+        if a.ndim != 2:
+            raise ValueError("mask shape %s, expected [H, W]" % (a.shape,))
+        out = np.empty_like(a)
+        self._check(self._L.vc_mask_morphology(self._ctx, _ptr(a, ctypes.c_uint8), a.shape[0], a.shape[1], int(ksize), int(bool(opening)),
+                                               int(bool(closing)), _ptr(out, ctypes.c_uint8)), "vc_mask_morphology")
+        return out
+
     def fetch_mask(self, cam, slot=0):
         out = np.empty(self.image_size, dtype=np.uint8)
         self._check(self._L.vc_fetch_mask(self._ctx, slot, cam, _ptr(out, ctypes.c_uint8)), "vc_fetch_mask")
