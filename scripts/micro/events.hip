@@ -66,6 +66,24 @@ int main()
             }
             sync(); printf("one stream, stop event on the first launch (%-16s) %6.2f us per round\n", fname[f], (now() - t0) / N * 1e6);
         }
+        // (g) the same chain with stream memory operations instead of events: write a counter behind A, the other stream waits for it
+        {
+            uint32_t *flags = nullptr, *flags2 = nullptr;           // (signal memory comes in 8-byte pieces)
+            CK(hipExtMallocWithFlags(reinterpret_cast<void **>(&flags), 8, hipMallocSignalMemory));
+            CK(hipExtMallocWithFlags(reinterpret_cast<void **>(&flags2), 8, hipMallocSignalMemory));
+            CK(hipMemset(flags, 0, 8)); CK(hipMemset(flags2, 0, 8));
+            sync(); t0 = now();
+            for (int i = 0; i < N; ++i) {
+                hipLaunchKernelGGL(k_small, dim3(64), dim3(256), 0, s1, d, 1u);
+                CK(hipStreamWriteValue32(s1, flags, (uint32_t)(i + 1), 0));
+                CK(hipStreamWaitValue32(s2, flags, (uint32_t)(i + 1), hipStreamWaitValueGte, 0xffffffffu));
+                hipLaunchKernelGGL(k_small, dim3(64), dim3(256), 0, s2, d + 64, 2u);
+                CK(hipStreamWriteValue32(s2, flags2, (uint32_t)(i + 1), 0));
+                CK(hipStreamWaitValue32(s1, flags2, (uint32_t)(i + 1), hipStreamWaitValueGte, 0xffffffffu));
+            }
+            sync(); printf("ping-pong across two streams, stream write / wait value %7.2f us per round\n", (now() - t0) / N * 1e6);
+            (void)hipFree(flags); (void)hipFree(flags2);
+        }
         // (f) any-order launch: B may start before A has finished (no barrier bit)
         sync(); t0 = now();
         for (int i = 0; i < N; ++i) {
