@@ -264,6 +264,8 @@ int vc_fetch_mesh(vc_ctx *ctx, float *verts, uint32_t *faces);
  * Unknown names or out-of-range values return VC_ERR_ARG. */
 int vc_set_option(vc_ctx *ctx, const char *name, int value);
 int vc_timing(vc_ctx *ctx, vc_timing_t *out);
+/* sizeof(vc_timing_t) as the library was built: a binding checks its own mirror of the struct against it before the first call. */
+uint32_t vc_timing_struct_size(void);
 /* Diagnostics of the last brick-pipeline carve (scripts/, DESIGN figures): out[0] bricks listed for a look at their words,
  * out[1] bricks that may hold survivors, out[2] bricks whose voxels all survive, out[3] bricks of the slab, out[4] brick
  * columns listed, out[5] tile words that took the per-voxel test; the rest 0. */

@@ -596,6 +596,69 @@ def voxcarve_unpack(rec):
     return unpack_records(rec)
 
 
+def test_kernel_times_and_work_counters_of_detail_steps(eng, cams, masks, frames):
+    """Option timing_detail: every launch of a step carries begin / end events of its own and the kernels count what they touch
+    (vc_timing_t::kernel_ms_sum, work) -- what bench.py picks the step's dominant kernel and its algorithmic bytes by.  The counts
+    must be the work itself: per-voxel table entries / projections between the undecided words' voxels and four times that, one
+    emit projection per survivor without the colour table; and the records stay the oracle's."""
+    grid = (64, 256, 64)                                         # a brick-pipeline shape
+    setup_real(eng, cams, masks, frames, grid)
+    eng.build_lut()
+    want = eng.carve(mode="lut")
+    rec = eng.fetch_records()
+    eng.set_option("timing_detail", 1)
+    eng.set_option("emit_busy", 2)
+    try:
+        for mode, table in (("lut", 1), ("fused", 1), ("fused", 0)):
+            eng.set_option("fused_color_table", table)
+            eng.timing(reset=True)
+            steps = 3
+            for _ in range(steps):
+                eng.touch_masks(0)
+                eng.carve_begin(mode=mode)
+                assert eng.carve_end() == want and np.array_equal(eng.fetch_records(), rec), (mode, table)
+            tm = eng.timing()
+            k, w = tm["kernels"], tm["work"]
+            for name in ("k_prep_pack", "k_prep_grid", "k_cull_bricks", "k_brick_words", "k_voxel_words", "k_assemble", "k_scan_groups",
+                         "k_finish_scan", "k_emit"):
+                assert k[name]["launches"] == steps and 0 < k[name]["ms_sum"] < 50, (mode, name, k.get(name))
+            words = eng.debug_counters()["words_undecided"]
+            assert w["brick_boxes"] > 0 and w["word_boxes"] > 0 and words > 0
+            asked = w["table_entries"] if mode == "lut" else w["projections"]
+            assert w["projections" if mode == "lut" else "table_entries"] == 0
+            assert steps * words * 64 * 0.2 <= asked <= steps * words * 64 * 4, (mode, asked, words)
+            assert w["emit_projections"] == (steps * want if (mode == "fused" and not table) else 0), (mode, table, w)
+    finally:
+        eng.set_option("timing_detail", 0)
+        eng.set_option("emit_busy", 1)
+        eng.set_option("fused_color_table", 1)
+
+
+def test_overflowed_step_is_not_expanded_from_a_newer_frame(built, cams, masks, frames):
+    """A step whose record buffer was too small is expanded again when it is collected -- from its frame set as it is THEN.  If a
+    later step has prepared that slot with new input in the meantime, the colours would be the newer frame's: the call fails by
+    name instead (and the context stays usable)."""
+    import voxcarve
+    from voxcarve._lib import VoxcarveError
+    full = [np.full_like(m, 255) for m in masks]                 # every voxel inside all four images survives: far more than n / 16 + 1024
+    with voxcarve.CarveEngine(0) as e:
+        e.set_grid(64, 64, 64)
+        e.set_cameras(cams, *masks[0].shape)
+        e.upload_masks(full)
+        e.upload_frame(1, frames[1])
+        e.carve_begin(mode="fused")                              # A: overflows its first-ever record buffer
+        e.upload_masks(masks)                                    # new input into the same slot ...
+        e.upload_frame(1, frames[2])
+        e.carve_begin(mode="fused")                              # ... prepared by B
+        with pytest.raises(VoxcarveError, match="prepared again"):
+            e.carve_end()
+        n_b = e.carve_end()                                      # B itself is fine
+        assert n_b == 6981
+        e.upload_masks(full)                                     # and the same overflow without interference regrows and succeeds
+        n_a = e.carve(mode="fused")
+        assert n_a > 64 ** 3 // 16 + 1024 and e.fetch_records().size == n_a
+
+
 def test_fetch_after_the_result_buffers_were_reissued_fails(eng, cams, masks, frames):
     """Three sets of result buffers: begin A, begin B, end (-> A collected), begin C (third set: A still there), begin D:
     D is queued into A's buffers, so A can no longer be fetched -- an error, never a mix of two steps."""

@@ -86,6 +86,7 @@ SIGNATURES = {
     "vc_marching_cubes": (ctypes.c_int, [c_ctx, c_u8p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_float, c_u64p, c_u64p]),
     "vc_fetch_mesh": (ctypes.c_int, [c_ctx, ctypes.POINTER(ctypes.c_float), c_u32p]),
     "vc_set_option": (ctypes.c_int, [c_ctx, ctypes.c_char_p, ctypes.c_int]),
+    "vc_timing_struct_size": (ctypes.c_uint32, []),
     "vc_timing": (ctypes.c_int, [c_ctx, ctypes.POINTER(VcTiming)]),
     "vc_debug_counters": (ctypes.c_int, [c_ctx, c_u64p]),
     "vc_timing_reset": (ctypes.c_int, [c_ctx]),
@@ -125,6 +126,9 @@ def load():
         fn = getattr(lib, name)          # AttributeError = ABI drift, let it surface
         fn.restype = restype
         fn.argtypes = argtypes
+    if lib.vc_timing_struct_size() != ctypes.sizeof(VcTiming):
+        raise VoxcarveError("libvoxcarve.so at %s was built with a vc_timing_t of %d bytes, this binding mirrors one of %d: rebuild the library"
+                            % (path, lib.vc_timing_struct_size(), ctypes.sizeof(VcTiming)))
     _lib = lib
     return lib
 

@@ -2205,6 +2205,8 @@ int vc_timing(vc_ctx *ctx, vc_timing_t *out)
     return VC_OK;
 }
 
+uint32_t vc_timing_struct_size(void) { return (uint32_t)sizeof(vc_timing_t); }
+
 int vc_timing_reset(vc_ctx *ctx)
 {
     if (!ctx) return VC_ERR_ARG;
