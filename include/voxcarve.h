@@ -236,6 +236,8 @@ int vc_fetch_mesh(vc_ctx *ctx, float *verts, uint32_t *faces);
  *                   refine_pair (1), reorder (1)  two cameras per round trip; most selective camera first
  *                   voxel_pairs (0)  per-voxel level of the brick pipeline: 0 = two cameras per round trip up to 4 cameras, one
  *                                  above; 1 = always two; 2 = always one
+ *                   voxel_batches (0 = 8 for table look-ups with two cameras per round, else 1)  batches of 8 undecided words a wave of
+ *                                  the per-voxel level takes one after the other
  *                   emit_lanes (1), emit_busy (1: grids >= 64 M voxels, 2: always, 0: never)  record expansion form
  *                   force_generic (0)  one thread per voxel everywhere (also env VOXCARVE_FORCE_GENERIC=1)
  *   frame sets      grid_lds_kb (0 = 16; frame sets above 2 MB of mask bits: what their uncropped grids need at the finest block

@@ -35,7 +35,7 @@ for s in range(NS):
     eng.upload_frame(1, np.roll(frames[1], 3 * s, axis=1), slot=s)
 if mode == "lut":
     eng.build_lut()
-DEFAULTS = {"stream_priority": 1, "reserve_cus": 0, "emit_waves_per_cu": 256, "overlap": 1, "event_scope": 1, "dbg": 0, "launch_events": 1, "kernel_events": 0, "timing_detail": 0}
+DEFAULTS = {"stream_priority": 1, "reserve_cus": 0, "emit_waves_per_cu": 256, "overlap": 1, "event_scope": 1, "dbg": 0, "launch_events": 1, "kernel_events": 0, "timing_detail": 0, "voxel_batches": 0}
 
 
 def run(n, depth=3):

@@ -1372,14 +1372,21 @@ __global__ __launch_bounds__(kBlock) void k_voxel_words(const CarveParams p, con
     const uint32_t nwaves = gridDim.x * (kBlock / 64);
     const uint32_t qpl = p.nx >> 2;
     uint64_t nstat = 0;
-    for (uint32_t t = wave0; t < nbatch; t += nwaves) {
-        // lane b < B fetches entry b of the batch; everybody gets them by cross-lane reads
+    // lane b < B fetches entry b of a batch; everybody gets them by cross-lane reads.  A wave that takes several batches has the
+    // next one's entries under way while it works on this one (one dependent round trip less per batch).
+    auto fetch = [&](uint32_t t, bool &valid) -> uint64_t {
         uint32_t shard, within, ssize;
-        shard_locate(sv, t, shard, within, ssize);
-        const bool mine_valid = lane < (uint32_t)B && within * B + lane < ssize;
+        shard_locate(sv, t < nbatch ? t : 0u, shard, within, ssize);
+        valid = t < nbatch && lane < (uint32_t)B && within * B + lane < ssize;
         const size_t at = (size_t)shard * bl.cap_w + within * B + lane;
-        uint64_t e0 = 0;
-        if (mine_valid) e0 = bl.words[at];
+        return valid ? bl.words[at] : 0ull;
+    };
+    bool nvalid = false;
+    uint64_t enext = nbatch ? fetch(wave0, nvalid) : 0ull;
+    for (uint32_t t = wave0; t < nbatch; t += nwaves) {
+        const bool mine_valid = nvalid;
+        const uint64_t e0 = enext;
+        enext = fetch(t + nwaves, nvalid);
         uint32_t nd[B], Tb[B];
         uint32_t alive = 0, ndany = 0;
 #pragma unroll

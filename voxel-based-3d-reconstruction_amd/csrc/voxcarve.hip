@@ -258,6 +258,7 @@ struct vc_ctx {
     int bricks = 1;                  // the brick pipeline where the grid shape allows (ny in {256, 512, 1024})
     int dbg = 0;
     bool big_lds_ok = false;
+    int voxel_batches = 0;                   // k_voxel_words: batches of 8 words a wave takes one after the other; 0 = by kernel form (launch_bricks)
     int voxel_pairs = 0;                     // k_voxel_words: 0 = by camera count, 1 = two cameras per round, 2 = one
     bool kbox_valid = false;
     int cull = 1;                    // hierarchical kernels on tile words: cull whole bricks first
@@ -606,7 +607,10 @@ int launch_bricks(vc_ctx *ctx, CarveParams &p, size_t lds, uint32_t ngroups)
     // many cameras: most voxels fail the first camera they ask, a second camera's entries read in the same round trip would be
     // wasted on them; few cameras: two per dependent round (the lists are short, the kernel is latency bound)
     const bool pairs = !LUT || ctx->voxel_pairs == 1 || (ctx->voxel_pairs == 0 && p.C <= 4);
-    const dim3 vgrid(sized(k_words, (uint64_t)p.nbrick_pad * 4, (uint64_t)p.nbrick_pad * 64, pairs ? 32 : 64));
+    // batches a wave takes one after the other (the next one's entries under way): 8 where a batch is short (table look-ups, two cameras
+    // per round: 0.1368 -> 0.1345 ms per step at 1024^3 x 4; 16: 0.147), 1 where it is long (projection 0.175 -> 0.19, one camera per round 0.30 -> 0.32)
+    const uint32_t vb = ctx->voxel_batches ? (uint32_t)ctx->voxel_batches : (LUT && pairs ? 8u : 1u);
+    const dim3 vgrid(sized(k_words, (uint64_t)p.nbrick_pad * 4, (uint64_t)p.nbrick_pad * 64, (pairs ? 32u : 64u) * vb));
     if (pairs) VC_KLAUNCH(VC_K_VOXEL_WORDS, (k_voxel_words<LUT, true>), vgrid, block, 0, ctx->stream, p, bl);
     else VC_KLAUNCH(VC_K_VOXEL_WORDS, (k_voxel_words<LUT, false>), vgrid, block, 0, ctx->stream, p, bl);
     VC_KLAUNCH(VC_K_ASSEMBLE, k_assemble, dim3(sized(k_cols == 0xffffffffu ? k_cols : k_cols * 16u, (uint64_t)ncolumns * 4, (uint64_t)ncolumns * 16, 4)),
@@ -2137,6 +2141,7 @@ int vc_set_option(vc_ctx *ctx, const char *name, int value)
     else if (k == "bricks") ctx->bricks = value != 0;
     else if (k == "dbg") ctx->dbg = value;
     else if (k == "voxel_pairs") ctx->voxel_pairs = value;
+    else if (k == "voxel_batches" && value >= 0 && value <= 16) ctx->voxel_batches = value;
     else if (k == "emit_busy" && value >= 0 && value <= 2) ctx->emit_busy = value;          // 0 never, 1 large grids, 2 always
     else if (k == "emit_waves_per_cu" && value >= 4 && value <= 1024) ctx->emit_waves_per_cu = value;
     else if (k == "lut_tile") ctx->lut_tile = value != 0;
