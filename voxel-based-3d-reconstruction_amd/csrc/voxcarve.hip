@@ -970,7 +970,9 @@ int enqueue_expand(vc_ctx *ctx, hipStream_t st, const uint64_t *d_entries, uint6
     VC_TRY(ensure(ctx, ctx->d_yoff, ngroups));
     VC_TRY(ensure(ctx, ctx->d_ybsum, kMaxScanBlocks));
     VC_TRY(ensure(ctx, ctx->d_yboff, kMaxScanBlocks + 1));
-    const bool from_lut = cur.mode == VC_MODE_LUT && cur.color_cam >= 0;
+    // (the table-free mode colours from the colour camera's table too, unless fused_color_table is off: the whole-grid table the
+    // expansion of other ranks' words needs is the very one)
+    const bool from_lut = (cur.mode == VC_MODE_LUT || ctx->fused_color_table) && cur.color_cam >= 0;
     if (from_lut && !(ctx->lut_color_cam == cur.color_cam && ctx->d_lut_color.ptr)) {
         VC_TRY(ensure_color_table(ctx, cur.color_cam));           // built on the first stream, once per camera
         if (st != ctx->stream) VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
