@@ -2360,10 +2360,12 @@ __device__ __forceinline__ void emit_prepare(const EmitParams &p, uint64_t &nz, 
 }
 
 // colour gathers and record stores of a prepared batch
-template <bool ALLSEEN, int EB, bool INDIRECT>
+// ROOM: the group's records (at most 4 096) all fit the buffer -- no test per record
+template <bool ALLSEEN, int EB, bool INDIRECT, bool ROOM = false>
 __device__ __forceinline__ void emit_finish(const EmitParams &p, uint64_t out0, uint64_t gw, uint32_t lane, const EmitBatch<EB> &B)
 {
     const uint64_t below = (1ull << lane) - 1ull;
+    uint64_t *__restrict__ grp = p.records + out0;                // (wave-uniform: the stores take a 32-bit offset from it)
     // all gathers of the batch are issued before any of them is used (a load consumed inside its own branch is waited for
     // inside it: eight round trips in a row)
     uint32_t mw[EB], px[EB];
@@ -2388,10 +2390,10 @@ __device__ __forceinline__ void emit_finish(const EmitParams &p, uint64_t out0, 
 #pragma unroll
     for (int b = 0; b < EB; ++b) {
         if (__builtin_amdgcn_inverse_ballot_w64(B.wv[b])) {
-            const uint64_t o = out0 + (B.wl[b] & 0xffffu) + (uint32_t)__popcll(B.wv[b] & below);
+            const uint32_t k = (B.wl[b] & 0xffffu) + (uint32_t)__popcll(B.wv[b] & below);
             // (streamed past the caches: 238 MB per step that nothing on the device reads again would evict the masks, images
             // and block grids the next kernels want)
-            if (o < p.capacity) __builtin_nontemporal_store(rec[b], &p.records[o]);
+            if (ROOM || out0 + k < p.capacity) __builtin_nontemporal_store(rec[b], &grp[k]);
         }
     }
 }
@@ -2421,7 +2423,7 @@ __device__ __forceinline__ EmitGroup emit_load_group(const EmitParams &p, uint32
 
 // The dependent chain of a batch is table entry -> pixel -> store; the next batch's table loads are issued before the
 // current batch's pixels are waited for, so a group of B batches costs about B + 1 round trips instead of 2 B.
-template <bool FROM_LUT, bool ALLSEEN, int EB, bool INDIRECT>
+template <bool FROM_LUT, bool ALLSEEN, int EB, bool INDIRECT, bool ROOM = false>
 __device__ __forceinline__ void emit_group_lanes(const EmitParams &p, const uint32_t g, const uint32_t lane, const EmitGroup &h)
 {
     const uint64_t gw = (uint64_t)g * kGroupWords;
@@ -2448,10 +2450,10 @@ __device__ __forceinline__ void emit_group_lanes(const EmitParams &p, const uint
     emit_prepare<FROM_LUT, EB, INDIRECT>(p, nz, h.mine, h.mybase, wstart, tbase, gw, lane, A);
     while (A.any) {                                                     // wave-uniform; A and B take turns (no copies)
         emit_prepare<FROM_LUT, EB, INDIRECT>(p, nz, h.mine, h.mybase, wstart, tbase, gw, lane, B);
-        emit_finish<ALLSEEN, EB, INDIRECT>(p, h.out0, gw, lane, A);
+        emit_finish<ALLSEEN, EB, INDIRECT, ROOM>(p, h.out0, gw, lane, A);
         if (!B.any) break;
         emit_prepare<FROM_LUT, EB, INDIRECT>(p, nz, h.mine, h.mybase, wstart, tbase, gw, lane, A);
-        emit_finish<ALLSEEN, EB, INDIRECT>(p, h.out0, gw, lane, B);
+        emit_finish<ALLSEEN, EB, INDIRECT, ROOM>(p, h.out0, gw, lane, B);
     }
 }
 
@@ -2485,7 +2487,9 @@ __global__ __launch_bounds__(kBlock) void k_emit_busy(const EmitParams p)
         const uint32_t g2 = t + 2 * nwaves < nbusy ? p.busylist[t + 2 * nwaves] : 0u;
         EmitGroup hn = h;
         if (more) hn = emit_load_group<false>(p, g1, lane);
-        emit_group_lanes<FROM_LUT, ALLSEEN, EB, false>(p, g, lane, h);
+        // (a group holds at most 4 096 records: where that many fit behind its first one, nothing is tested per record)
+        if (FROM_LUT && h.out0 + 4096u <= p.capacity) emit_group_lanes<FROM_LUT, ALLSEEN, EB, false, true>(p, g, lane, h);
+        else emit_group_lanes<FROM_LUT, ALLSEEN, EB, false>(p, g, lane, h);
         h = hn; g = g1; g1 = g2;
     }
 }
