@@ -1419,10 +1419,16 @@ __global__ __launch_bounds__(kBlock) void k_voxel_words(const CarveParams p, con
                     off2[b] = t2 ? __builtin_nontemporal_load(&L2[(size_t)Tb[b] * 64]) : -2;
                     if (p.stats) nstat += (uint64_t)__popcll(__ballot(t1)) + (uint64_t)__popcll(__ballot(t2));
                 }
+                // (the value of a lane that asks nothing is set first, branch-free; ONE lane mask -- "has an entry" -- around the gather)
 #pragma unroll
                 for (int b = 0; b < B; ++b) {
-                    mw[b] = (off[b] >= 0) ? mb[(uint32_t)off[b] >> 5] : (off[b] == -2 ? ~0u : 0u);
-                    mw2[b] = !PAIR ? ~0u : (off2[b] >= 0) ? mb2[(uint32_t)off2[b] >> 5] : (off2[b] == -2 ? ~0u : 0u);
+                    mw[b] = off[b] == -2 ? ~0u : 0u;
+                    mw2[b] = (!PAIR || off2[b] == -2) ? ~0u : 0u;
+                }
+#pragma unroll
+                for (int b = 0; b < B; ++b) {
+                    if (off[b] >= 0) mw[b] = mb[(uint32_t)off[b] >> 5];
+                    if (PAIR && off2[b] >= 0) mw2[b] = mb2[(uint32_t)off2[b] >> 5];
                 }
 #pragma unroll
                 for (int b = 0; b < B; ++b)
