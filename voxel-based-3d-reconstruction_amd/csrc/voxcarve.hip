@@ -2404,13 +2404,14 @@ int vc_allgather(vc_ctx *ctx, uint64_t *counts_out, uint64_t *total_out)
     VC_TRY(finish_gather(ctx));
     if (ctx->sb[ctx->cur].no_records)
         return fail(ctx, VC_ERR_ARG, "last carve ran with VC_FLAG_NO_RECORDS: the record exchange needs records");
+    hipStream_t sx = ctx->overlap ? ctx->stream_x : ctx->stream;      // (the exchange stream: every collective of the communicator is queued there)
     uint64_t *d_mine = ctx->d_counts.ptr + G;
     *ctx->h_total = ctx->survivors;
-    VC_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    VC_HIP(ctx, hipMemcpyAsync(d_mine, ctx->h_total, sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-    VC_NCCL(ctx, g_rccl.AllGather(d_mine, ctx->d_counts.ptr, 1, ncclUint64, ctx->comm, ctx->stream));
-    VC_HIP(ctx, hipMemcpyAsync(ctx->h_counts, ctx->d_counts.ptr, sizeof(uint64_t) * G, hipMemcpyDeviceToHost, ctx->stream));
-    VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    VC_HIP(ctx, hipEventRecord(ctx->ev[0], sx));
+    VC_HIP(ctx, hipMemcpyAsync(d_mine, ctx->h_total, sizeof(uint64_t), hipMemcpyHostToDevice, sx));
+    VC_NCCL(ctx, g_rccl.AllGather(d_mine, ctx->d_counts.ptr, 1, ncclUint64, ctx->comm, sx));
+    VC_HIP(ctx, hipMemcpyAsync(ctx->h_counts, ctx->d_counts.ptr, sizeof(uint64_t) * G, hipMemcpyDeviceToHost, sx));
+    VC_HIP(ctx, hipStreamSynchronize(sx));
     uint64_t total = 0;
     for (int r = 0; r < G; ++r) total += ctx->h_counts[r];
     VC_TRY(ensure(ctx, ctx->d_gathered, (size_t)total));
@@ -2422,7 +2423,7 @@ int vc_allgather(vc_ctx *ctx, uint64_t *counts_out, uint64_t *total_out)
         const uint64_t cnt = ctx->h_counts[r];
         if (cnt) {
             ncclResult_t rc = g_rccl.Broadcast(cur.records.ptr, ctx->d_gathered.ptr + disp, cnt, ncclUint64, r,
-                                               ctx->comm, ctx->stream);
+                                               ctx->comm, sx);
             if (rc != ncclSuccess) {
                 g_rccl.GroupEnd();
                 return fail(ctx, VC_ERR_RCCL, "ncclBroadcast(root %d): %s", r, g_rccl.GetErrorString(rc));
@@ -2431,8 +2432,8 @@ int vc_allgather(vc_ctx *ctx, uint64_t *counts_out, uint64_t *total_out)
         disp += cnt;
     }
     VC_NCCL(ctx, g_rccl.GroupEnd());
-    VC_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-    VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    VC_HIP(ctx, hipEventRecord(ctx->ev[1], sx));
+    VC_HIP(ctx, hipStreamSynchronize(sx));
     VC_HIP(ctx, hipEventElapsedTime(&ctx->tm.gather_ms, ctx->ev[0], ctx->ev[1]));
     ctx->tm.exchange_ms = ctx->tm.gather_ms;
     ctx->tm.gather_ms_sum += ctx->tm.gather_ms;
@@ -2453,10 +2454,11 @@ int vc_comm_allreduce_max(vc_ctx *ctx, double *inout)
     VC_HIP(ctx, hipSetDevice(ctx->device));
     VC_TRY(ensure(ctx, ctx->d_scratch, 16));
     double *d = ctx->d_scratch.ptr;
-    VC_HIP(ctx, hipMemcpyAsync(d, inout, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    VC_NCCL(ctx, g_rccl.AllReduce(d, d + 1, 1, ncclFloat64, ncclMax, ctx->comm, ctx->stream));
-    VC_HIP(ctx, hipMemcpyAsync(inout, d + 1, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    hipStream_t sx = ctx->overlap ? ctx->stream_x : ctx->stream;      // (every collective of the communicator on the one exchange stream)
+    VC_HIP(ctx, hipMemcpyAsync(d, inout, sizeof(double), hipMemcpyHostToDevice, sx));
+    VC_NCCL(ctx, g_rccl.AllReduce(d, d + 1, 1, ncclFloat64, ncclMax, ctx->comm, sx));
+    VC_HIP(ctx, hipMemcpyAsync(inout, d + 1, sizeof(double), hipMemcpyDeviceToHost, sx));
+    VC_HIP(ctx, hipStreamSynchronize(sx));
     return VC_OK;
 }
 
