@@ -1298,10 +1298,12 @@ __global__ __launch_bounds__(kBlock) void k_brick_boxes_bm(const CarveParams p, 
     }
 }
 
-__global__ __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_brick_words(const CarveParams p, const BrickLists bl)
+// DUAL: the 1024-thread form for block grids that fill the LDS (one workgroup per compute unit, four waves per SIMD, 128 registers each).  At that
+// occupancy nothing hides a brick's chain of rounds {four cameras' boxes, four box tests}: a wave takes TWO listed bricks at a time and
+// interleaves their rounds, so that one brick's box loads are under way while the other's boxes are tested.
+template <int NB>
+__device__ __forceinline__ void brick_words_body(const CarveParams &p, const BrickLists &bl, uint32_t *s_grid)
 {
-    if (p.dbg & 72u) return;
-    extern __shared__ uint32_t s_grid[];
     uint32_t *cnt = bl.counters + bl.parity * 3 * kShards * kShardStride;
     const ShardView sv = shard_view(cnt, 1, threadIdx.x & 63u);
     const uint32_t nlist = sv.total;
@@ -1316,46 +1318,82 @@ __global__ __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu(8, 8
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t nwaves = gridDim.x * (blockDim.x / 64);
     const uint32_t qpl = p.nx >> 2, nzl = (uint32_t)(p.n / ((uint64_t)p.nx * p.ny));
+    const bool tests = !(p.dbg & 6u);
     uint64_t nstat = 0;
-    for (uint32_t t = wave0; t < nlist; t += nwaves) {
-        uint32_t shard, within, ssize;
-        shard_locate(sv, t, shard, within, ssize);
-        const uint32_t b = hdr_u32(bl.bricks, shard * bl.cap_b + within);
-        const uint32_t col = b / p.tq, by = b - col * p.tq, bz = col / p.nbx, bx = col - bz * p.nbx;     // wave-uniform
-        const uint32_t qx = 4 * bx + (lane >> 4), izl = 16 * bz + (lane & 15u);
-        bool cand = qx < qpl && izl < nzl;
-        uint32_t need = 0;                                        // by camera NUMBER (k_voxel_words has no use for the order)
-        const size_t slot = (size_t)b * 64 + lane;
-        for (uint32_t q0 = 0; q0 < p.C && __ballot(cand) != 0 && !(p.dbg & 6u); q0 += 4) {
-            uint64_t bb[4];
-            uint32_t cn[4];
-            if (p.stats) nstat += (uint64_t)__popcll(__ballot(cand)) * (p.C - q0 < 4u ? p.C - q0 : 4u);
+    for (uint32_t t0 = wave0; t0 < nlist; t0 += NB * nwaves) {
+        uint32_t b[NB], need[NB];
+        bool cand[NB], exists[NB], have[NB];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                cn[k] = q0 + k < p.C ? ord(s_order, q0 + k) : 0u;
-                bb[k] = (q0 + k < p.C && cand) ? bl.wbox[(size_t)cn[k] * p.nbrick_pad * 64 + slot] : 0ull;
+        for (int i = 0; i < NB; ++i) {
+            const uint32_t t = t0 + (uint32_t)i * nwaves;
+            have[i] = t < nlist;                                   // (wave-uniform)
+            uint32_t shard, within, ssize;
+            shard_locate(sv, have[i] ? t : t0, shard, within, ssize);
+            b[i] = hdr_u32(bl.bricks, shard * bl.cap_b + within);
+            const uint32_t col = b[i] / p.tq, bz = col / p.nbx, bx = col - bz * p.nbx;     // wave-uniform
+            exists[i] = have[i] && 4 * bx + (lane >> 4) < qpl && 16 * bz + (lane & 15u) < nzl;
+            cand[i] = exists[i];
+            need[i] = 0;                                           // by camera NUMBER (k_voxel_words has no use for the order)
+        }
+        for (uint32_t q0 = 0; q0 < p.C && tests; q0 += 4) {
+            bool any = false;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) any = any || __ballot(cand[i]) != 0;
+            if (!any) break;
+            uint64_t bb[NB][4];
+            uint32_t cn[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cn[k] = q0 + k < p.C ? ord(s_order, q0 + k) : 0u;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                if (p.stats) nstat += (uint64_t)__popcll(__ballot(cand[i])) * (p.C - q0 < 4u ? p.C - q0 : 4u);
+                const size_t slot = (size_t)b[i] * 64 + lane;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    bb[i][k] = (q0 + k < p.C && cand[i]) ? bl.wbox[(size_t)cn[k] * p.nbrick_pad * 64 + slot] : 0ull;
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (q0 + k < p.C && cand) {
-                    const uint32_t r = box_test(s_grid, load_gridcam(s_grid, cn[k]), bb[k], gshift);
-                    cand = r != 0;
-                    if (r == 1) need |= 1u << cn[k];
+            for (int i = 0; i < NB; ++i) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (q0 + k < p.C && cand[i]) {
+                        const uint32_t r = box_test(s_grid, load_gridcam(s_grid, cn[k]), bb[i][k], gshift);
+                        cand[i] = r != 0;
+                        if (r == 1) need[i] |= 1u << cn[k];
+                    }
                 }
             }
         }
-        if (!cand) need = 0;
-        else if (passall) need = (1u << p.C) - 1u;
-        const bool exists = qx < qpl && izl < nzl;
-        const uint64_t T = ((uint64_t)(exists ? izl : 0u) * qpl + (exists ? qx : 0u)) * p.tq + by;
-        if (exists && (need == 0 || (p.dbg & 1u))) bl.bm[T] = cand ? ~0ull : 0ull;     // decided here
-        const uint64_t um = (p.dbg & 1u) ? 0ull : __ballot(need != 0);
-        if (um) {
-            const size_t o = shard_append(cnt + 2 * kShards * kShardStride, bl.cap_w, t % kShards, um, lane);
-            if (need) bl.words[o] = T | ((uint64_t)need << 32);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            if (!have[i]) continue;
+            const uint32_t col = b[i] / p.tq, by = b[i] - col * p.tq, bz = col / p.nbx, bx = col - bz * p.nbx;
+            const uint32_t qx = 4 * bx + (lane >> 4), izl = 16 * bz + (lane & 15u);
+            if (!cand[i]) need[i] = 0;
+            else if (passall) need[i] = (1u << p.C) - 1u;
+            const uint64_t T = ((uint64_t)(exists[i] ? izl : 0u) * qpl + (exists[i] ? qx : 0u)) * p.tq + by;
+            if (exists[i] && (need[i] == 0 || (p.dbg & 1u))) bl.bm[T] = cand[i] ? ~0ull : 0ull;     // decided here
+            const uint64_t um = (p.dbg & 1u) ? 0ull : __ballot(need[i] != 0);
+            if (um) {
+                const size_t o = shard_append(cnt + 2 * kShards * kShardStride, bl.cap_w, (t0 + (uint32_t)i * nwaves) % kShards, um, lane);
+                if (need[i]) bl.words[o] = T | ((uint64_t)need[i] << 32);
+            }
         }
     }
     stat_add(p.stats, 0 /* VC_WORK_WORD_BOXES */, wave0, lane, nstat);
+}
+
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_brick_words(const CarveParams p, const BrickLists bl)
+{
+    if (p.dbg & 72u) return;
+    extern __shared__ uint32_t s_grid[];
+    brick_words_body<1>(p, bl, s_grid);
+}
+__global__ __launch_bounds__(kWideBlock) void k_brick_words_wide(const CarveParams p, const BrickLists bl)
+{
+    if (p.dbg & 72u) return;
+    extern __shared__ uint32_t s_grid[];
+    brick_words_body<4>(p, bl, s_grid);
 }
 
 // B undecided words per wave (list entries B t .. B t + B - 1), lanes = the 64 voxels of a tile word (4 x-rows x 16 y).

@@ -599,11 +599,12 @@ int launch_bricks(vc_ctx *ctx, CarveParams &p, size_t lds, uint32_t ngroups)
     if (word_wgs > lds_cap) word_wgs = lds_cap;
     if (lds > kMaxFirstLds && !ctx->big_lds_ok) {                             // more than 64 KB of dynamic LDS is opt-in
         VC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cull_bricks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxWideLds));
-        VC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_brick_words), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxWideLds));
+        VC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_brick_words_wide), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxWideLds));
         ctx->big_lds_ok = true;
     }
     VC_KLAUNCH(VC_K_CULL_BRICKS, k_cull_bricks, dim3(cull_wgs), gblock, lds, ctx->stream, p, bl, ngroups);
-    VC_KLAUNCH(VC_K_BRICK_WORDS, k_brick_words, dim3(word_wgs), gblock, lds, ctx->stream, p, bl);
+    if (wide) VC_KLAUNCH(VC_K_BRICK_WORDS, k_brick_words_wide, dim3(word_wgs), gblock, lds, ctx->stream, p, bl);
+    else VC_KLAUNCH(VC_K_BRICK_WORDS, k_brick_words, dim3(word_wgs), gblock, lds, ctx->stream, p, bl);
     // many cameras: most voxels fail the first camera they ask, a second camera's entries read in the same round trip would be
     // wasted on them; few cameras: two per dependent round (the lists are short, the kernel is latency bound)
     const bool pairs = !LUT || ctx->voxel_pairs == 1 || (ctx->voxel_pairs == 0 && p.C <= 4);
