@@ -140,6 +140,8 @@ struct CarveParams {
     uint32_t C, H, W, mwords;
     uint32_t min_views;
     unsigned long long *stats;  // option timing_detail: work counters (stat_add), else null
+    uint32_t cull_lds_words;    // k_cull_bricks: u32 words of dynamic LDS it was launched with when that is an ESTIMATE of the coarse grids' length
+                                // (0: the launch reserved what the grids can take at most); grids that turn out longer are not staged at all
     uint32_t dbg;               // experiments only (vc_set_option("dbg", ...), scripts/exp_bricks.py): 1 = skip the voxel level (undecided words
                                 // count as alive), 2 = skip the word level too; 8 = preparation, carve and scan kernels launch and return
                                 // at once (32 / 64 / 128 / 256 / 512: only the preparation / cull + word level / voxel level /
@@ -1206,12 +1208,16 @@ __global__ __launch_bounds__(kWideBlock) void k_cull_bricks(const CarveParams p,
 {
     if (p.dbg & 72u) return;                                       // experiment: launch only (scripts/exp_streams.py)
     extern __shared__ uint32_t s_grid[];
-    stage_grids(s_grid, p.coarsegrid ? p.coarsegrid : p.blockgrid);
+    const uint32_t *gsrc = p.coarsegrid ? p.coarsegrid : p.blockgrid;
+    // (the launch sized its LDS from a bound on the coarse grids that oddly shaped crops can exceed: then nothing is staged and every
+    // brick is listed for the word level, which decides it all the same -- slower, never wrong)
+    const bool staged = p.cull_lds_words == 0 || hdr_u32(gsrc, kHdrWords) + 8u <= p.cull_lds_words;
+    if (staged) stage_grids(s_grid, gsrc);
     __shared__ uint32_t s_order[kMaxCameras];
     stage_order(p.counts, p.C, s_order);
     if (blockIdx.x == 0 && threadIdx.x < 3 * kShards) bl.counters[((bl.parity ^ 1u) * 3 * kShards + threadIdx.x) * kShardStride] = 0;
     uint32_t *cnt = bl.counters + bl.parity * 3 * kShards * kShardStride;
-    const uint32_t gshift = hdr_u32(s_grid, kHdrShift);
+    const uint32_t gshift = staged ? hdr_u32(s_grid, kHdrShift) : 0u;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t nwaves = gridDim.x * (blockDim.x / 64);
@@ -1230,8 +1236,8 @@ __global__ __launch_bounds__(kWideBlock) void k_cull_bricks(const CarveParams p,
         for (uint32_t it = 0; it < ipw; ++it) {
             const uint32_t w = W * ipw + it;
             const uint32_t b = w * 64 + lane;
-            bool cand = b < nbricks, full = true;
-            for (uint32_t q0 = 0; q0 < p.C && __ballot(cand) != 0; q0 += 4) {
+            bool cand = b < nbricks, full = staged;
+            for (uint32_t q0 = 0; q0 < p.C && __ballot(cand) != 0 && staged; q0 += 4) {
                 uint64_t bb[4];
                 if (p.stats) nstat += (uint64_t)__popcll(__ballot(cand)) * (p.C - q0 < 4u ? p.C - q0 : 4u);
 #pragma unroll

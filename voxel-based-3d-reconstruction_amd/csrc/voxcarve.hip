@@ -255,6 +255,7 @@ struct vc_ctx {
     uint64_t mc_verts = 0, mc_faces = 0;
     bool mc_valid = false;
     uint32_t list_parity = 0;
+    uint32_t cull_probe = 0;         // steps that skipped the brick-level tests (launch_bricks: every 64th looks again)
     int bricks = 1;                  // the brick pipeline where the grid shape allows (ny in {256, 512, 1024})
     int dbg = 0;
     bool big_lds_ok = false;
@@ -602,7 +603,29 @@ int launch_bricks(vc_ctx *ctx, CarveParams &p, size_t lds, uint32_t ngroups)
         VC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_brick_words_wide), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxWideLds));
         ctx->big_lds_ok = true;
     }
-    VC_KLAUNCH(VC_K_CULL_BRICKS, k_cull_bricks, dim3(cull_wgs), gblock, lds, ctx->stream, p, bl, ngroups);
+    // Frame sets on which the brick level decides next to nothing (16 noisy cameras: every brick's box holds some foreground block
+    // in every camera) pay its 35 us for nothing: when the earlier step whose list lengths are known listed at least nine bricks in ten,
+    // this step lists them all without looking (the kernel stages no grids and tests no boxes; the word level decides them all the
+    // same), and every 64th such step looks again.  Work only, never results.
+    const uint32_t nbricks_all = p.nbx * p.tq * p.nbz;
+    const bool cull_pays = k_bricks == 0xffffffffu || (uint64_t)k_bricks * 10u < (uint64_t)nbricks_all * 9u || (ctx->cull_probe++ & 63u) == 0u;
+    if (!cull_pays || (ctx->dbg & 8192)) {
+        p.cull_lds_words = 1;                                     // (nothing fits: nothing is staged)
+        const uint32_t w4 = nw / (kBlock / 64);
+        VC_KLAUNCH(VC_K_CULL_BRICKS, k_cull_bricks, dim3(w4 < 1 ? 1u : (w4 > 1024 ? 1024u : w4)), block, 64, ctx->stream, p, bl, ngroups);
+        p.cull_lds_words = 0;
+    }
+    else if (wide && p.coarsegrid) {
+        // the brick level reads the 4 x 4 times coarser grids (about a sixteenth of the words): no reason to share an LDS copy among 16
+        // waves -- with nw / 16 workgroups it ran on 32 of the 256 compute units at 512^3.  Ordinary workgroups, as many as there are
+        // wave loads of bricks; the bound on the coarse grids' length: a sixteenth of the fine ones + one more row and column per camera
+        const size_t clds = ((size_t)(lds / sizeof(uint32_t)) / 8 + 64u * p.C + kGridHeader + 8) * sizeof(uint32_t);
+        const uint32_t w4 = nw / (kBlock / 64);
+        p.cull_lds_words = (uint32_t)((clds < lds ? clds : lds) / sizeof(uint32_t));      // (an estimate: the kernel checks it against the real length)
+        VC_KLAUNCH(VC_K_CULL_BRICKS, k_cull_bricks, dim3(w4 < 1 ? 1u : (w4 > 1024 ? 1024u : w4)), block, clds < lds ? clds : lds, ctx->stream, p, bl, ngroups);
+        p.cull_lds_words = 0;
+    }
+    else VC_KLAUNCH(VC_K_CULL_BRICKS, k_cull_bricks, dim3(cull_wgs), gblock, lds, ctx->stream, p, bl, ngroups);
     if (wide) VC_KLAUNCH(VC_K_BRICK_WORDS, k_brick_words_wide, dim3(word_wgs), gblock, lds, ctx->stream, p, bl);
     else VC_KLAUNCH(VC_K_BRICK_WORDS, k_brick_words, dim3(word_wgs), gblock, lds, ctx->stream, p, bl);
     // many cameras: most voxels fail the first camera they ask, a second camera's entries read in the same round trip would be
