@@ -251,6 +251,9 @@ int vc_fetch_mesh(vc_ctx *ctx, float *verts, uint32_t *faces);
  *   experiments     dbg (0)  bit 0: skip the per-voxel level (undecided words count as alive), bit 1: skip the word level
  *                                  too -- WRONG results on purpose, to time the levels apart (scripts/exp_bricks.py); bit 2:
  *                                  no word-level tests, every word of a listed brick goes to the per-voxel level (right results)
+ *                                  bit 13: the brick level lists every brick without testing (what it does by itself once a step has
+ *                                  listed nine bricks in ten), bit 14: wide frame sets without the survivors' compaction at the word
+ *                                  level -- right results, other paths (tests)
  *   timing          timing_detail (0)  1: vc_carve_begin steps record the events around preparation and carve kernels too
  *                                  (vc_carve always does; see vc_timing_t), every kernel carries begin / end events on its own
  *                                  launch (kernel_ms_sum) and counts its work (vc_timing_t::work)

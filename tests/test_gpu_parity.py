@@ -287,9 +287,10 @@ def test_config5_full_size_512_cubed_16_cameras_1080p(eng):
         for mode in ("lut", "fused"):
             # block grids of 32, 16 and 8 px (the last: 138 KB of LDS shared by 1024-thread workgroups, the default for this frame
             # set); the per-voxel level asking one camera per round (default above 4 cameras) and two
-            # (dbg 8192: k_cull_bricks stages nothing and lists every brick for the word level, as it does by itself once a step has
+            # (dbg 16384: the word level with four bricks in lockstep instead of the survivors' compaction;
+            #  dbg 8192: k_cull_bricks stages nothing and lists every brick for the word level, as it does by itself once a step has
             # listed nine bricks in ten -- this frame set -- and as it would if its LDS estimate turned out too small)
-            for lds, pairs, dbg in ((16, 0, 0), (64, 0, 0), (148, 0, 0), (148, 1, 0), (0, 2, 0), (0, 0, 8192)):
+            for lds, pairs, dbg in ((16, 0, 0), (64, 0, 0), (148, 0, 0), (148, 1, 0), (0, 2, 0), (0, 0, 8192), (0, 0, 16384)):
                 eng.set_option("grid_lds_kb", lds)
                 eng.set_option("voxel_pairs", pairs)
                 eng.set_option("dbg", dbg)

@@ -141,6 +141,7 @@ struct CarveParams {
     uint32_t min_views;
     unsigned long long *stats;  // option timing_detail: work counters (stat_add), else null
     uint32_t cull_lds_words;    // k_cull_bricks: u32 words of dynamic LDS it was launched with when that is an ESTIMATE of the coarse grids' length
+    uint32_t compact_off;       // k_brick_words_wide: where the waves' compaction words start in the dynamic LDS (u32 words; 0: no room, bricks in lockstep)
                                 // (0: the launch reserved what the grids can take at most); grids that turn out longer are not staged at all
     uint32_t dbg;               // experiments only (vc_set_option("dbg", ...), scripts/exp_bricks.py): 1 = skip the voxel level (undecided words
                                 // count as alive), 2 = skip the word level too; 8 = preparation, carve and scan kernels launch and return
@@ -392,6 +393,65 @@ __device__ __forceinline__ uint32_t box_test(const uint32_t *__restrict__ grids,
     }
     if (any == 0) return 0;
     return (miss == 0 && (bb & kBoxAllInside)) ? 2u : 1u;
+}
+
+// The same answers for large images, where a word's box is often five or six block rows tall and box_test's loop (one row and one
+// grid word per dependent trip, taken by the whole wave as soon as one lane has such a box) was a good part of k_brick_words at
+// 512^3 x 16 x 1080p: a box up to 32 blocks wide is a 64-bit window on two neighbouring grid words, two rows per trip, every
+// lane making the trips of the tallest box among the wave's (rows past a lane's box repeat its last row).  The neighbour of
+// the first or last kept word may lie outside the camera's rectangle: read all the same (LDS; before the first row that is the
+// word in front of the grid), never looked at (its half of the window is empty).
+// N boxes side by side against one camera (the lanes' N list entries of one trip of brick_words_compact): no branches, one row
+// loop for all.  Boxes wider than 32 blocks are undecided here (box_test looks at up to 64: work, not results).
+constexpr uint32_t kRowsPerTrip = 2;
+template <int N>
+__device__ __forceinline__ void box_test_rows_n(const uint32_t *__restrict__ grids, const GridCam gc, const uint64_t (&bb)[N], const bool (&on)[N],
+                                                uint32_t gshift, uint32_t (&res)[N])
+{
+    const uint32_t cw_hi = (uint32_t)gc.w_lo + gc.cws - 1u, cv_hi = (uint32_t)gc.v_lo + gc.ch - 1u;
+    const uint32_t *__restrict__ g_any = grids + gc.off;
+    const uint32_t *__restrict__ g_all = g_any + (uint32_t)gc.ch * gc.cws;
+    uint32_t mlo[N], mhi[N], miss[N], any[N], nr[N], fixed[N];
+    int32_t i0[N];
+    bool look[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const bool live = on[j] && bb[j] != kEmptyBox && gc.ch != 0;
+        const uint32_t bu0 = (uint32_t)(bb[j] & 0xffffu) >> gshift, bv0 = (uint32_t)((bb[j] >> 16) & 0xffffu) >> gshift;
+        const uint32_t bu1 = (uint32_t)((bb[j] >> 32) & 0xffffu) >> gshift, bv1 = (uint32_t)((bb[j] >> 48) & 0x7fffu) >> gshift;
+        const uint32_t w0 = bu0 >> 5, w1 = bu1 >> 5;
+        const bool near = live && !(w1 < gc.w_lo || w0 > cw_hi || bv1 < gc.v_lo || bv0 > cv_hi);
+        const bool big = bv1 - bv0 > 15u || bu1 - bu0 > 31u;
+        look[j] = near && !big;
+        fixed[j] = near && big ? 1u : 0u;                           // the answer of a test that does not look at the grids
+        const uint32_t r0 = bv0 > gc.v_lo ? bv0 : gc.v_lo, r1 = bv1 < cv_hi ? bv1 : cv_hi;
+        miss[j] = (r0 != bv0 || r1 != bv1) ? 1u : 0u;
+        const uint64_t m = ((2ull << ((bu1 - bu0) & 31u)) - 1ull) << (bu0 & 31u);
+        mlo[j] = (uint32_t)m; mhi[j] = (uint32_t)(m >> 32);
+        if (w0 < gc.w_lo) { miss[j] = 1u; mlo[j] = 0u; }
+        if (w0 + 1u > cw_hi) { miss[j] |= mhi[j]; mhi[j] = 0u; }
+        if (!look[j]) { mlo[j] = 0u; mhi[j] = 0u; }
+        i0[j] = look[j] ? (int32_t)__umul24(r0 - gc.v_lo, gc.cws) + (int32_t)w0 - (int32_t)gc.w_lo : 0;
+        nr[j] = look[j] ? r1 - r0 : 0u;
+        any[j] = 0u;
+    }
+    uint32_t nrmax = nr[0];
+#pragma unroll
+    for (int j = 1; j < N; ++j) nrmax = nr[j] > nrmax ? nr[j] : nrmax;
+    for (uint32_t k = 0; __ballot(k <= nrmax) != 0ull; k += kRowsPerTrip) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+#pragma unroll
+            for (uint32_t rr = 0; rr < kRowsPerTrip; ++rr) {
+                const int32_t ia = i0[j] + (int32_t)__umul24(k + rr < nr[j] ? k + rr : nr[j], gc.cws);
+                any[j] |= (g_any[ia] & mlo[j]) | (g_any[ia + 1] & mhi[j]);
+                miss[j] |= (~g_all[ia] & mlo[j]) | (~g_all[ia + 1] & mhi[j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+        res[j] = !look[j] ? fixed[j] : any[j] == 0u ? 0u : (miss[j] == 0u && (bb[j] & kBoxAllInside)) ? 2u : 1u;
 }
 
 // Sum over the 64 lanes with data-parallel-primitive moves (no trip through the LDS crossbar: six ds_bpermute in a row cost
@@ -1389,6 +1449,134 @@ __device__ __forceinline__ void brick_words_body(const CarveParams &p, const Bri
     stat_add(p.stats, 0 /* VC_WORK_WORD_BOXES */, wave0, lane, nstat);
 }
 
+// The 1024-thread form where the LDS has 256 more words per wave (CarveParams::compact_off) and a camera mask fits in 24 bits.
+// Most words meet the camera that rejects them in the first round (the cameras are asked in order of emptiness) and the rest of
+// a brick's rounds would run with a few lanes alive.  The words of four listed bricks -- {brick i, lane, need} in 32 bits --
+// are packed into the wave's LDS words, tested 64 NP at a time, side by side (box_test_rows_n), the survivors packed again in
+// place after every round; at the end they are scattered back to their own lanes, so that the stores stay whole rows.
+// One copy of the test code for all rounds (the unrolled lockstep form of four bricks is 10 000 instructions: more than the
+// instruction cache).  One wave's LDS operations execute in order; the fences are for the compiler.
+template <int NP>
+__device__ __forceinline__ void brick_words_compact(const CarveParams &p, const BrickLists &bl, uint32_t *s_grid)
+{
+    constexpr int NB = 4;
+    uint32_t *cnt = bl.counters + bl.parity * 3 * kShards * kShardStride;
+    const ShardView sv = shard_view(cnt, 1, threadIdx.x & 63u);
+    const uint32_t nlist = sv.total;
+    if (blockIdx.x == 0 && threadIdx.x == 0) bl.host_counts[0] = nlist;
+    if (blockIdx.x * (blockDim.x / 64) >= nlist) return;
+    const bool passall = (p.dbg & 4u) != 0;
+    stage_grids(s_grid, p.blockgrid);
+    __shared__ uint32_t s_order[kMaxCameras];
+    stage_order(p.counts, p.C, s_order);
+    const uint32_t gshift = passall ? 0u : hdr_u32(s_grid, kHdrShift);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t below = (1ull << lane) - 1ull;
+    const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const uint32_t nwaves = gridDim.x * (blockDim.x / 64);
+    const uint32_t qpl = p.nx >> 2, nzl = (uint32_t)(p.n / ((uint64_t)p.nx * p.ny));
+    const bool tests = !(p.dbg & 6u);
+    uint32_t *scr = s_grid + p.compact_off + (threadIdx.x >> 6) * 256u;
+    uint64_t nstat = 0;
+    for (uint32_t t0 = wave0; t0 < nlist; t0 += NB * nwaves) {
+        uint32_t b[NB];
+        bool exists[NB], have[NB];
+        uint32_t n = 0;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const uint32_t t = t0 + (uint32_t)i * nwaves;
+            have[i] = t < nlist;                                   // (wave-uniform)
+            uint32_t shard, within, ssize;
+            shard_locate(sv, have[i] ? t : t0, shard, within, ssize);
+            b[i] = hdr_u32(bl.bricks, shard * bl.cap_b + within);
+            const uint32_t col = b[i] / p.tq, bz = col / p.nbx, bx = col - bz * p.nbx;
+            exists[i] = have[i] && 4 * bx + (lane >> 4) < qpl && 16 * bz + (lane & 15u) < nzl;
+            const uint64_t m = __ballot(exists[i]);
+            if (exists[i]) scr[n + (uint32_t)__popcll(m & below)] = ((uint32_t)i << 6) | lane;
+            n += (uint32_t)__popcll(m);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (uint32_t q0 = 0; q0 < p.C && n != 0u && tests; q0 += 4) {
+            uint32_t cn[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cn[k] = q0 + k < p.C ? ord(s_order, q0 + k) : 0u;
+            uint32_t nout = 0;
+#pragma nounroll
+            for (uint32_t base = 0; base < n; base += 64 * NP) {
+                uint32_t e[NP], nd[NP]; bool c[NP]; uint64_t bb[4][NP];
+#pragma unroll
+                for (int u = 0; u < NP; ++u) {
+                    c[u] = base + 64u * u + lane < n;
+                    e[u] = c[u] ? scr[base + 64u * u + lane] : 0u;
+                    nd[u] = e[u] >> 8;
+                    const uint32_t bi = (e[u] >> 6) & 3u;
+                    const uint32_t bsel = bi == 0u ? b[0] : bi == 1u ? b[1] : bi == 2u ? b[2] : b[3];
+                    const size_t slot = (size_t)bsel * 64 + (e[u] & 63u);
+                    if (p.stats) nstat += (uint64_t)__popcll(__ballot(c[u])) * (p.C - q0 < 4u ? p.C - q0 : 4u);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        bb[k][u] = (q0 + k < p.C && c[u]) ? bl.wbox[(size_t)cn[k] * p.nbrick_pad * 64 + slot] : 0ull;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (q0 + k >= p.C) break;
+                    bool some = false;
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) some = some || c[u];
+                    if (__ballot(some) == 0ull) break;
+                    uint32_t r[NP];
+                    box_test_rows_n<NP>(s_grid, load_gridcam(s_grid, cn[k]), bb[k], c, gshift, r);
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) {
+                        if (c[u] && r[u] == 1u) nd[u] |= 1u << cn[k];
+                        c[u] = c[u] && r[u] != 0u;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < NP; ++u) {
+                    const uint64_t m = __ballot(c[u]);              // (the survivors land at or below what this trip has read)
+                    if (c[u]) scr[nout + (uint32_t)__popcll(m & below)] = (e[u] & 255u) | (nd[u] << 8);
+                    nout += (uint32_t)__popcll(m);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+            n = nout;
+        }
+        uint32_t ent[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) ent[i] = 64u * i + lane < n ? scr[64u * i + lane] : 0xffffffffu;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int i = 0; i < NB; ++i) scr[64u * i + lane] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int i = 0; i < NB; ++i) if (ent[i] != 0xffffffffu) scr[ent[i] & 255u] = (ent[i] >> 8) | 0x80000000u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        uint32_t res[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) res[i] = scr[64u * i + lane];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            if (!have[i]) continue;
+            const bool cand = exists[i] && (res[i] >> 31);
+            uint32_t need = cand ? res[i] & 0x7fffffffu : 0u;
+            if (cand && passall) need = (1u << p.C) - 1u;
+            const uint32_t col = b[i] / p.tq, by = b[i] - col * p.tq, bz = col / p.nbx, bx = col - bz * p.nbx;
+            const uint32_t qx = 4 * bx + (lane >> 4), izl = 16 * bz + (lane & 15u);
+            const uint64_t T = ((uint64_t)(exists[i] ? izl : 0u) * qpl + (exists[i] ? qx : 0u)) * p.tq + by;
+            if (exists[i] && (need == 0 || (p.dbg & 1u))) bl.bm[T] = cand ? ~0ull : 0ull;       // decided here
+            const uint64_t um = (p.dbg & 1u) ? 0ull : __ballot(need != 0);
+            if (um) {
+                const size_t o = shard_append(cnt + 2 * kShards * kShardStride, bl.cap_w, (t0 + (uint32_t)i * nwaves) % kShards, um, lane);
+                if (need) bl.words[o] = T | ((uint64_t)need << 32);
+            }
+        }
+    }
+    stat_add(p.stats, 0 /* VC_WORK_WORD_BOXES */, wave0, lane, nstat);
+}
+
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_brick_words(const CarveParams p, const BrickLists bl)
 {
     if (p.dbg & 72u) return;
@@ -1399,7 +1587,8 @@ __global__ __launch_bounds__(kWideBlock) void k_brick_words_wide(const CarvePara
 {
     if (p.dbg & 72u) return;
     extern __shared__ uint32_t s_grid[];
-    brick_words_body<4>(p, bl, s_grid);
+    if (p.compact_off) brick_words_compact<2>(p, bl, s_grid);
+    else brick_words_body<4>(p, bl, s_grid);
 }
 
 // B undecided words per wave (list entries B t .. B t + B - 1), lanes = the 64 voxels of a tile word (4 x-rows x 16 y).

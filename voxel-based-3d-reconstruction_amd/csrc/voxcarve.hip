@@ -600,7 +600,7 @@ int launch_bricks(vc_ctx *ctx, CarveParams &p, size_t lds, uint32_t ngroups)
     if (word_wgs > lds_cap) word_wgs = lds_cap;
     if (lds > kMaxFirstLds && !ctx->big_lds_ok) {                             // more than 64 KB of dynamic LDS is opt-in
         VC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cull_bricks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxWideLds));
-        VC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_brick_words_wide), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxWideLds));
+        VC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_brick_words_wide), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kMaxWideLds + 6 * 1024)));
         ctx->big_lds_ok = true;
     }
     // Frame sets on which the brick level decides next to nothing (16 noisy cameras: every brick's box holds some foreground block
@@ -626,7 +626,15 @@ int launch_bricks(vc_ctx *ctx, CarveParams &p, size_t lds, uint32_t ngroups)
         p.cull_lds_words = 0;
     }
     else VC_KLAUNCH(VC_K_CULL_BRICKS, k_cull_bricks, dim3(cull_wgs), gblock, lds, ctx->stream, p, bl, ngroups);
-    if (wide) VC_KLAUNCH(VC_K_BRICK_WORDS, k_brick_words_wide, dim3(word_wgs), gblock, lds, ctx->stream, p, bl);
+    if (wide) {
+        // + 1 KB per wave for the survivors' compaction (vc_kernels.h, brick_words_body) where the LDS has it: a camera mask and a lane number in 32 bits
+        const size_t grid_words = (lds / sizeof(uint32_t) + 63u) & ~(size_t)63u;
+        const size_t with = (grid_words + (kWideBlock / 64) * 256u) * sizeof(uint32_t);
+        const bool compact = with <= kMaxWideLds + 6 * 1024 && p.C > 4 && p.C <= 23 && !(ctx->dbg & 16384);
+        p.compact_off = compact ? (uint32_t)grid_words : 0u;
+        VC_KLAUNCH(VC_K_BRICK_WORDS, k_brick_words_wide, dim3(word_wgs), gblock, compact ? with : lds, ctx->stream, p, bl);
+        p.compact_off = 0;
+    }
     else VC_KLAUNCH(VC_K_BRICK_WORDS, k_brick_words, dim3(word_wgs), gblock, lds, ctx->stream, p, bl);
     // many cameras: most voxels fail the first camera they ask, a second camera's entries read in the same round trip would be
     // wasted on them; few cameras: two per dependent round (the lists are short, the kernel is latency bound)
