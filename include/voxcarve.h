@@ -196,8 +196,8 @@ int vc_fetch_viewmask(vc_ctx *ctx, uint16_t *viewmask);
 int vc_fetch_occupancy(vc_ctx *ctx, uint8_t *bits);
 
 /* ---- the step before the path, its data-parallel part ------------------------------------------------------
- * Front half of extract_foreground_mask, background_subtraction.py:153-168.  Host buffers in and out (the stateful background
- * model, bg_model.apply :158, and findContours / fill :171-193 sit between these calls and stay with cv2 on the CPU).
+ * Front half of extract_foreground_mask, background_subtraction.py:153-168.  Host buffers in and out (findContours / fill
+ * :171-193 sits between the pre- and the post-filter and stays with cv2 on the CPU).
  * vc_bgr_to_hsv: replaces cv2.cvtColor(image, cv2.COLOR_BGR2HSV) (:155) on uint8 [H,W,3] -- OpenCV's 8-bit fixed-point
  * conversion (H in 0..179).  vc_mask_morphology: replaces cv2.morphologyEx(mask, MORPH_OPEN / MORPH_CLOSE,
  * getStructuringElement(MORPH_RECT, (ksize, ksize))) on uint8 [H,W], opening first when both flags are set: ksize 3 = the
@@ -205,6 +205,20 @@ int vc_fetch_occupancy(vc_ctx *ctx, uint8_t *bits);
  * vc_set_mask_postfilter).  Parity with cv2 is unpinned (oracle/foreground_np.py restates OpenCV's published code). */
 int vc_bgr_to_hsv(vc_ctx *ctx, const uint8_t *bgr, uint32_t H, uint32_t W, uint8_t *hsv);
 int vc_mask_morphology(vc_ctx *ctx, const uint8_t *mask, uint32_t H, uint32_t W, uint32_t ksize, int open, int close, uint8_t *out);
+/* The background model between them: cv2.bgsegm.createBackgroundSubtractorMOG(history, nmixtures, backgroundRatio, noiseSigma)
+ * (background_subtraction.py:75-76; assignment.py:79 trains one per camera) and its apply(image, None, learningRate)
+ * (:91 training, :158 inference with learning rate 0) on uint8 [H,W,3] images -> uint8 [H,W] {0, 255}.  The model lives on the
+ * device (8 floats per mixture and pixel); it starts over on its first frame, on a learning rate >= 1 and when the image size
+ * changes; a negative learning rate means 1 / min(frames seen, history), as in OpenCV.  Non-positive constructor arguments select
+ * OpenCV's defaults (history 200, 5 mixtures (at most 8), backgroundRatio 0.95 when not given, noiseSigma 15).  vc_mog_state
+ * copies the model out ([8 nmixtures][H W] float planes: plane 8 k + f = field f of component k; f: 0 sort key, 1 weight,
+ * 2..4 mean, 5..7 variance; state may be null to ask for the sizes only) -- tests and persistence.  Restated from the published
+ * algorithm of opencv_contrib's bgsegm module (bgfg_gaussmix.cpp); parity with cv2 unpinned (oracle/mog_np.py). */
+#define VC_MAX_MOG_MODELS 64
+int vc_mog_create(vc_ctx *ctx, int history, int nmixtures, double background_ratio, double noise_sigma, uint32_t *model);
+int vc_mog_apply(vc_ctx *ctx, uint32_t model, const uint8_t *image, uint32_t H, uint32_t W, double learning_rate, uint8_t *fgmask);
+int vc_mog_state(vc_ctx *ctx, uint32_t model, float *state, uint64_t capacity, uint32_t *H, uint32_t *W, uint32_t *nmixtures, uint32_t *nframes);
+int vc_mog_destroy(vc_ctx *ctx, uint32_t model);
 
 /* ---- the step after the path: marching cubes over the dense ON/OFF volume -------------------------------
  * Replaces skimage.measure.marching_cubes(voxels_status, 0) of plot_marching_cubes, voxel_reconstruction.py:127-163, whose

@@ -434,6 +434,71 @@ def test_foreground_front_half_on_device(eng, frames):
         bs.extract_foreground_mask(img, Model(), engine=eng)
 
 
+def _mog_frames(rng, shape, n):
+    """A background of a few flat regions + texture, sensor noise, a second mode that comes and goes, a moving square."""
+    H, W = shape
+    bg = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    bg[: H // 2] = (bg[: H // 2] // 8) + 100
+    alt = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    out = []
+    for t in range(n):
+        f = (alt if t % 5 == 4 else bg).astype(np.int64) + rng.integers(-6, 7, (H, W, 3))
+        if t >= n // 2 and H > 8 and W > 8:
+            y, x = (3 * t) % (H - 6), (5 * t) % (W - 6)
+            f[y:y + 6, x:x + 6] = 255 - f[y:y + 6, x:x + 6]
+        out.append(np.clip(f, 0, 255).astype(np.uint8))
+    return out
+
+
+def test_mog_background_model_on_device(eng):
+    """SURVEY 8(f)-2, bg_model.apply (background_subtraction.py:158) and the model's training (:75-92): the device model after every
+    frame -- mask AND all 8 floats of every mixture of every pixel, bit for bit -- against oracle/mog_np.py, through training with the
+    automatic learning rate, a fixed one, inference with learning rate 0 (model untouched), a restart on learning rate 1 and on a
+    new image size; the vectorised restatement against the literal per-pixel one on the small size.  Parity with cv2: unpinned."""
+    from oracle import mog_np
+    from voxcarve import background_subtraction as bs
+    rng = np.random.default_rng(77)
+    for shape, kw in (((486, 644), {}), ((9, 13), dict(history=7, nmixtures=3, backgroundRatio=0.6, noiseSigma=4)),
+                      ((64, 50), dict(nmixtures=8, backgroundRatio=0.9)), ((1, 1), dict(nmixtures=1))):
+        dev = bs.BackgroundSubtractorMOG(engine=eng, **kw)
+        ref = mog_np.MOG(**kw)
+        lit = mog_np.MOGLiteral(**kw) if shape == (9, 13) else None
+        frames = _mog_frames(rng, shape, 24)
+        rates = [-1] * 12 + [0.05] * 4 + [0, 0] + [1.0] + [-1] * 3 + [0, 0.3]
+        mixed = False
+        for t, (f, lr) in enumerate(zip(frames, rates)):
+            got, want = dev.apply(f, None, lr), ref.apply(f, lr)
+            mixed = mixed or 0 < (want > 0).mean() < 1
+            assert got.dtype == np.uint8 and np.array_equal(got, want), (shape, t, lr, int((got != want).sum()))
+            state, hw, nf = dev.state()
+            assert hw == shape and nf == ref.nframes
+            assert np.array_equal(state.view(np.uint32), ref.state.view(np.uint32)), (shape, t, lr)
+            if lit is not None:
+                assert np.array_equal(lit.apply(f, lr), want) and np.array_equal(lit.state.view(np.uint32), ref.state.view(np.uint32))
+        assert mixed or shape == (1, 1)                        # (some frame had both foreground and background)
+        # a new image size starts the model over, as apply() does
+        f2 = rng.integers(0, 256, (shape[0] + 1, shape[1], 3), dtype=np.uint8)
+        assert np.array_equal(dev.apply(f2, None, 0), ref.apply(f2, 0)) and dev.state()[2] == 1
+        dev.close()
+    # the drop-in training loop (frames handed in: no video decoder here) + extract_foreground_mask with the device model
+    frames = _mog_frames(rng, (120, 160), 16)
+    model = bs.train_MOG_background_model(frames=frames[:12], engine=eng)
+    ref = mog_np.MOG()
+    from oracle import foreground_np as fg, postfilter_np as pf
+    for f in frames[:12]:
+        ref.apply(fg.bgr_to_hsv(f), -1)
+    assert np.array_equal(model.state()[0].view(np.uint32), ref.state.view(np.uint32))
+    keep = lambda mask, a, b: np.where(mask == 255, 255, 0).astype(np.uint8)
+    got = bs.extract_foreground_mask(frames[14], model, 0, 5000, 115, True, True, True, True, engine=eng, contour_stage=keep)
+    want = pf.post_filter(keep(fg.pre_filter(ref.apply(fg.bgr_to_hsv(frames[14]), 0), True, True), 0, 0), True, True)
+    assert np.array_equal(got, want) and got.any()
+    from voxcarve._lib import VoxcarveError
+    with pytest.raises(VoxcarveError, match="cv2"):           # decoding the reference's background.avi needs cv2: absent here, and says so
+        bs.train_MOG_background_model("data/cam1", "background.avi", engine=eng)
+    with pytest.raises(VoxcarveError, match="no background model"):
+        eng.mog_apply(63, frames[0], 0)
+
+
 def test_cropped_block_grid_edge_cases(eng, cams, masks, frames):
     """The block grids keep only the blocks around each camera's foreground (word-aligned columns, block rows):
     foreground confined to a corner pixel, the last row / column, one pixel wide lines, two far-apart blobs,

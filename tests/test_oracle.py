@@ -256,3 +256,28 @@ def test_foreground_restatement_hsv_and_3x3_morphology():
             assert ero[y, x] == win.min() and dil[y, x] == win.max()
     assert np.array_equal(fg.pre_filter(img), img)
     assert np.array_equal(fg.pre_filter(img, True, True), fg.erode3x3(fg.dilate3x3(fg.dilate3x3(fg.erode3x3(img)))))
+
+
+def test_mog_restatement_vectorised_equals_literal_and_behaves():
+    """oracle/mog_np.py (parity with cv2 unpinned): the vectorised restatement of bgsegm's MOG against the literal per-pixel one --
+    masks and every float of the state, bit for bit -- and the model's behaviour on what it is for: a static noisy background
+    becomes background, a new object on it is foreground under learning rate 0, and learning rate 0 leaves the model untouched."""
+    from oracle import mog_np
+    rng = np.random.default_rng(5)
+    bg = rng.integers(0, 256, (10, 14, 3), dtype=np.uint8)
+    for kw in ({}, dict(history=5, nmixtures=2, backgroundRatio=0.5, noiseSigma=3), dict(nmixtures=8)):
+        a, b = mog_np.MOG(**kw), mog_np.MOGLiteral(**kw)
+        for t in range(22):
+            f = rng.integers(0, 256, bg.shape).astype(np.uint8) if t % 6 == 4 else np.clip(bg.astype(int) + rng.integers(-15, 16, bg.shape), 0, 255).astype(np.uint8)
+            lr = -1 if t < 12 else (0.1 if t < 18 else 0)
+            assert np.array_equal(a.apply(f, lr), b.apply(f, lr)), (kw, t)
+            assert np.array_equal(a.state.view(np.uint32), b.state.view(np.uint32)), (kw, t)
+    m = mog_np.MOG()
+    for t in range(40):
+        mask = m.apply(np.clip(bg.astype(int) + rng.integers(-3, 4, bg.shape), 0, 255).astype(np.uint8), -1)
+    assert not mask.any()
+    before = m.state.copy()
+    f = bg.copy(); f[2:6, 3:9] = 255 - f[2:6, 3:9]
+    mask = m.apply(f, 0)
+    assert mask[2:6, 3:9].all() and mask.sum() == 255 * 24 and np.array_equal(before, m.state)
+    assert m.apply(f, -1)[2:6, 3:9].all()                       # a first sighting while learning is still foreground

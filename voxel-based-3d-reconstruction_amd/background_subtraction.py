@@ -1,17 +1,21 @@
-"""The reference's ``extract_foreground_mask`` (background_subtraction.py:129-208) with its data-parallel stages on the GPU.
+"""The reference's ``extract_foreground_mask`` (background_subtraction.py:129-208) and its MOG background model
+(``train_MOG_background_model``, :49-92) with their data-parallel stages on the GPU.
 
-SURVEY 8(f)-2, the step BEFORE the carve path.  Same name, parameters and defaults as the reference's function.  What runs where:
+SURVEY 8(f)-2, the step BEFORE the carve path.  Same names, parameters and defaults as the reference's functions.  What runs where:
 
   BGR -> HSV (:155)                      GPU   CarveEngine.bgr_to_hsv          (OpenCV's 8-bit fixed-point conversion)
-  bg_model.apply (:158)                  CPU   the caller's cv2 background model: a stateful mixture model, frame after frame
+  bg_model.apply (:158)                  GPU   BackgroundSubtractorMOG.apply   (the model assignment.py:79 trains; per pixel mixture
+                                               of Gaussians, state in HBM) -- or whatever model the caller hands in (a cv2 MOG2 / KNN
+                                               object works as before, on the CPU)
   3x3 open / close before the contours   GPU   CarveEngine.mask_morphology(.., 3, ..)
   contours: fill the figures, re-open
   their large holes (:171-193)           CPU   cv2.findContours / fillPoly / drawContours: sequential border following
   2x2 open / close after them (:195-203) GPU   CarveEngine.mask_morphology(.., 2, ..)
   final threshold (:206)                 host  one comparison
 
-The two CPU stages need cv2 (opencv-contrib, as the reference does); without it the call fails by name -- there is no
-substitute for them in this package.  Parity of the GPU stages with cv2 is unpinned (see oracle/foreground_np.py)."""
+The CPU stage needs cv2 (as the reference does), and so does decoding the training video; without it those calls fail by name --
+there is no substitute for them in this package.  Parity of the GPU stages with cv2 is unpinned (see oracle/foreground_np.py,
+oracle/mog_np.py)."""
 import numpy as np
 
 from ._lib import VoxcarveError
@@ -25,6 +29,74 @@ def _default_engine():
         from .engine import CarveEngine
         _engine = CarveEngine(0)
     return _engine
+
+
+class BackgroundSubtractorMOG:
+    """cv2.bgsegm.createBackgroundSubtractorMOG(history, nmixtures, backgroundRatio, noiseSigma) with the model on the device
+    (background_subtraction.py:75-76).  ``apply(image, fgmask=None, learningRate=-1)`` as cv2's: uint8 [H,W,3] in, uint8 [H,W]
+    {0, 255} out; -1 = 1 / min(frames seen, history), 0 = the model is only read (the reference's inference, :158)."""
+
+    def __init__(self, history=200, nmixtures=5, backgroundRatio=0.7, noiseSigma=0, engine=None):
+        self._eng = engine if engine is not None else _default_engine()
+        self._model = self._eng.mog_create(history, nmixtures, backgroundRatio, noiseSigma)
+
+    def apply(self, image, fgmask=None, learningRate=-1):
+        out = self._eng.mog_apply(self._model, image, learningRate)
+        if fgmask is not None:
+            fgmask[...] = out
+            return fgmask
+        return out
+
+    def state(self):
+        return self._eng.mog_state(self._model)
+
+    def close(self):
+        if self._model is not None:
+            self._eng.mog_destroy(self._model)
+            self._model = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _video_frames(path):
+    try:
+        import cv2
+    except ImportError as exc:
+        raise VoxcarveError("train_MOG_background_model: decoding %s runs on cv2.VideoCapture, which is not importable here (%s); "
+                            "pass the frames themselves (frames=...)" % (path, exc))
+    cap = cv2.VideoCapture(path)
+    if not cap.isOpened():
+        return None
+
+    def gen():
+        while True:
+            ok, frame = cap.read()
+            if not ok:
+                return
+            yield frame
+    return gen()
+
+
+def train_MOG_background_model(bg_video_input_path="data/cam", bg_video_input_filename="background.avi", use_hsv=True,
+                               history=200, n_mixtures=5, bg_ratio=0.7, noise_sigma=0, learning_rate=-1, engine=None, frames=None):
+    """A MOG model trained on a background video; reference background_subtraction.py:49-92, same parameters (None if the video
+    cannot be opened, as there).  ``frames``: an iterable of BGR frames instead of the video file (no cv2 needed then)."""
+    import os
+    if frames is None:
+        frames = _video_frames(os.path.join(bg_video_input_path, bg_video_input_filename))
+        if frames is None:
+            return None
+    eng = engine if engine is not None else _default_engine()
+    model = BackgroundSubtractorMOG(history=history, nmixtures=n_mixtures, backgroundRatio=bg_ratio, noiseSigma=noise_sigma, engine=eng)
+    for frame in frames:
+        if use_hsv:
+            frame = eng.bgr_to_hsv(frame)
+        model.apply(frame, None, learning_rate)
+    return model
 
 
 def fill_figures(mask, figure_threshold, figure_inner_threshold):

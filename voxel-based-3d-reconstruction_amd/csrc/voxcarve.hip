@@ -330,6 +330,13 @@ struct vc_ctx {
 
     DevBuf<uint8_t> d_fg;            // vc_bgr_to_hsv / vc_mask_morphology: input | output | scratch images
     DevBuf<int32_t> d_hsvdiv;        // OpenCV's two division tables of the 8-bit HSV conversion (sdiv | hdiv)
+    struct MogModel {                // vc_mog_*: one background model (the reference keeps one per camera, assignment.py:79)
+        bool used = false;
+        int history = 200, nmixtures = 5;
+        double background_ratio = 0.7, noise_sigma = 15.0;
+        uint32_t H = 0, W = 0, nframes = 0;
+        DevBuf<float> state;         // [8 nmixtures][H W] planes, see k_mog_apply
+    } mog[VC_MAX_MOG_MODELS];
     vc_timing_t tm;
     StepBuf *kev_sb = nullptr;       // timing_detail: the step whose kernels are being queued (their launches carry its per-kind events)
     DevBuf<unsigned long long> d_stats;   // timing_detail: the kernels' work counters, [VC_WORK_KINDS][kShards][kStatStride]
@@ -1141,6 +1148,7 @@ int vc_destroy(vc_ctx *ctx)
             for (int i = 0; i < 2; ++i) if (b.kev[kk][i]) (void)hipEventDestroy(b.kev[kk][i]);
     }
     release(ctx->d_stats); release(ctx->d_fg); release(ctx->d_hsvdiv);
+    for (auto &m : ctx->mog) release(m.state);
     release(ctx->d_viewmask); release(ctx->d_scratch); release(ctx->d_counts); release(ctx->d_gathered);
     release(ctx->d_ent_all[0]); release(ctx->d_ent_all[1]); release(ctx->d_xcnt); release(ctx->d_xoff); release(ctx->d_xbsum);
     release(ctx->d_xboff); release(ctx->d_lut_color);
@@ -2141,6 +2149,92 @@ int vc_mask_morphology(vc_ctx *ctx, const uint8_t *mask, uint32_t H, uint32_t W,
     VC_HIP(ctx, hipGetLastError());
     VC_HIP(ctx, hipMemcpyAsync(out, a, npix, hipMemcpyDeviceToHost, st));
     VC_HIP(ctx, hipStreamSynchronize(st));
+    return VC_OK;
+}
+
+int vc_mog_create(vc_ctx *ctx, int history, int nmixtures, double background_ratio, double noise_sigma, uint32_t *model)
+{
+    if (!ctx || !model) return VC_ERR_ARG;
+    for (uint32_t i = 0; i < VC_MAX_MOG_MODELS; ++i) {
+        vc_ctx::MogModel &m = ctx->mog[i];
+        if (m.used) continue;
+        // the constructor's clamps (bgfg_gaussmix.cpp, BackgroundSubtractorMOGImpl): non-positive arguments select the defaults
+        m.nmixtures = nmixtures > 0 ? nmixtures : 5;
+        if (m.nmixtures > kMogMaxMixtures) m.nmixtures = kMogMaxMixtures;
+        m.history = history > 0 ? history : 200;
+        m.background_ratio = background_ratio > 0 ? background_ratio : 0.95;
+        if (m.background_ratio > 1.0) m.background_ratio = 1.0;
+        m.noise_sigma = noise_sigma <= 0 ? 15.0 : noise_sigma;
+        m.H = m.W = m.nframes = 0;
+        m.used = true;
+        *model = i;
+        return VC_OK;
+    }
+    return fail(ctx, VC_ERR_ARG, "all %d background models of this context are in use", VC_MAX_MOG_MODELS);
+}
+
+int vc_mog_destroy(vc_ctx *ctx, uint32_t model)
+{
+    if (!ctx) return VC_ERR_ARG;
+    if (model >= VC_MAX_MOG_MODELS || !ctx->mog[model].used) return fail(ctx, VC_ERR_ARG, "no background model %u", model);
+    VC_HIP(ctx, hipSetDevice(ctx->device));
+    VC_HIP(ctx, hipStreamSynchronize(ctx->stream_up));
+    release(ctx->mog[model].state);
+    ctx->mog[model].used = false;
+    return VC_OK;
+}
+
+int vc_mog_apply(vc_ctx *ctx, uint32_t model, const uint8_t *image, uint32_t H, uint32_t W, double learning_rate, uint8_t *fgmask)
+{
+    if (!ctx || !image || !fgmask) return VC_ERR_ARG;
+    if (model >= VC_MAX_MOG_MODELS || !ctx->mog[model].used) return fail(ctx, VC_ERR_ARG, "no background model %u", model);
+    if (H == 0 || W == 0 || (uint64_t)H * W > 0x0fffffffull) return fail(ctx, VC_ERR_ARG, "image size %u x %u", H, W);
+    vc_ctx::MogModel &m = ctx->mog[model];
+    VC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t npix = (size_t)H * W;
+    hipStream_t st = ctx->stream_up;
+    // apply(): the model starts over on its first frame, on a learning rate >= 1 and when the image size changes
+    if (m.nframes == 0 || learning_rate >= 1 || m.H != H || m.W != W) {
+        VC_TRY(ensure(ctx, m.state, npix * 8 * (size_t)m.nmixtures));
+        VC_HIP(ctx, hipMemsetAsync(m.state.ptr, 0, npix * 8 * (size_t)m.nmixtures * sizeof(float), st));
+        m.H = H; m.W = W; m.nframes = 0;
+    }
+    ++m.nframes;
+    const double lr = learning_rate >= 0 && m.nframes > 1 ? learning_rate : 1.0 / (double)(m.nframes < (uint32_t)m.history ? m.nframes : (uint32_t)m.history);
+    const double default_noise_sigma = 30 * 0.5, w0 = 0.05;
+    MogParams p;
+    p.alpha = (float)lr; p.T = (float)m.background_ratio; p.vT = (float)(2.5 * 2.5);
+    p.w0 = (float)w0;
+    p.sk0 = (float)(w0 / (default_noise_sigma * 2 * std::sqrt(3.)));
+    p.var0 = (float)(default_noise_sigma * default_noise_sigma * 4);
+    p.minVar = (float)(m.noise_sigma * m.noise_sigma);
+    p.K = (uint32_t)m.nmixtures; p.npix = (uint32_t)npix;
+    VC_TRY(ensure(ctx, ctx->d_fg, npix * 6 + 64));
+    uint8_t *d_in = ctx->d_fg.ptr, *d_out = d_in + npix * 3;
+    VC_HIP(ctx, hipMemcpyAsync(d_in, image, npix * 3, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_mog_apply, dim3((uint32_t)((npix + 255) / 256)), dim3(256), 0, st, (const uint8_t *)d_in, d_out, m.state.ptr, p);
+    VC_HIP(ctx, hipGetLastError());
+    VC_HIP(ctx, hipMemcpyAsync(fgmask, d_out, npix, hipMemcpyDeviceToHost, st));
+    VC_HIP(ctx, hipStreamSynchronize(st));
+    return VC_OK;
+}
+
+int vc_mog_state(vc_ctx *ctx, uint32_t model, float *state, uint64_t capacity, uint32_t *H, uint32_t *W, uint32_t *nmixtures, uint32_t *nframes)
+{
+    if (!ctx) return VC_ERR_ARG;
+    if (model >= VC_MAX_MOG_MODELS || !ctx->mog[model].used) return fail(ctx, VC_ERR_ARG, "no background model %u", model);
+    const vc_ctx::MogModel &m = ctx->mog[model];
+    if (H) *H = m.H;
+    if (W) *W = m.W;
+    if (nmixtures) *nmixtures = (uint32_t)m.nmixtures;
+    if (nframes) *nframes = m.nframes;
+    if (!state) return VC_OK;
+    const size_t nfloat = (size_t)m.H * m.W * 8 * (size_t)m.nmixtures;
+    if (capacity < nfloat) return fail(ctx, VC_ERR_ARG, "state buffer holds %llu floats, the model has %llu", (unsigned long long)capacity, (unsigned long long)nfloat);
+    if (nfloat == 0) return VC_OK;
+    VC_HIP(ctx, hipSetDevice(ctx->device));
+    VC_HIP(ctx, hipStreamSynchronize(ctx->stream_up));
+    VC_HIP(ctx, hipMemcpy(state, m.state.ptr, nfloat * sizeof(float), hipMemcpyDeviceToHost));
     return VC_OK;
 }
 

@@ -147,6 +147,36 @@ class CarveEngine:
                                                int(bool(closing)), _ptr(out, ctypes.c_uint8)), "vc_mask_morphology")
         return out
 
+    # ---- the MOG background model (cv2.bgsegm.createBackgroundSubtractorMOG; background_subtraction.py:75-92, :158)
+    def mog_create(self, history=200, nmixtures=5, background_ratio=0.7, noise_sigma=0):
+        model = ctypes.c_uint32(0)
+        self._check(self._L.vc_mog_create(self._ctx, int(history), int(nmixtures), float(background_ratio), float(noise_sigma),
+                                          ctypes.byref(model)), "vc_mog_create")
+        return model.value
+
+    def mog_apply(self, model, image, learning_rate=-1):
+        a = np.ascontiguousarray(image, dtype=np.uint8)
+        if a.ndim != 3 or a.shape[2] != 3:
+            raise ValueError("image shape %s, expected [H, W, 3]" % (a.shape,))
+        out = np.empty(a.shape[:2], dtype=np.uint8)
+        self._check(self._L.vc_mog_apply(self._ctx, int(model), _ptr(a, ctypes.c_uint8), a.shape[0], a.shape[1], float(learning_rate),
+                                         _ptr(out, ctypes.c_uint8)), "vc_mog_apply")
+        return out
+
+    def mog_state(self, model):
+        """(state float32 [8 nmixtures, H W] planes -- plane 8 k + f: field f (sort key, weight, mean[3], var[3]) of component k --,
+        (H, W), frames seen)."""
+        H, W, K, nf = (ctypes.c_uint32(0) for _ in range(4))
+        self._check(self._L.vc_mog_state(self._ctx, int(model), None, 0, ctypes.byref(H), ctypes.byref(W), ctypes.byref(K), ctypes.byref(nf)),
+                    "vc_mog_state")
+        state = np.zeros((8 * K.value, H.value * W.value), dtype=np.float32)
+        if state.size:
+            self._check(self._L.vc_mog_state(self._ctx, int(model), _ptr(state, ctypes.c_float), state.size, None, None, None, None), "vc_mog_state")
+        return state, (H.value, W.value), nf.value
+
+    def mog_destroy(self, model):
+        self._check(self._L.vc_mog_destroy(self._ctx, int(model)), "vc_mog_destroy")
+
     def fetch_mask(self, cam, slot=0):
         out = np.empty(self.image_size, dtype=np.uint8)
         self._check(self._L.vc_fetch_mask(self._ctx, slot, cam, _ptr(out, ctypes.c_uint8)), "vc_fetch_mask")
