@@ -38,10 +38,15 @@ if mode == "lut":
 DEFAULTS = {"stream_priority": 1, "reserve_cus": 0, "emit_waves_per_cu": 256, "overlap": 1, "event_scope": 1, "dbg": 0, "launch_events": 1, "kernel_events": 0, "timing_detail": 0, "voxel_batches": 0}
 
 
+AHEAD = 0                                  # frame sets prepared this many steps before the step that carves them (the slots are there)
+
+
 def run(n, depth=3):
     pending = 0
+    for a in range(AHEAD):
+        eng.touch_masks(a % NS)
     for i in range(n):
-        eng.touch_masks(i % NS)
+        eng.touch_masks((i + AHEAD) % NS)
         eng.carve_begin(slot=i % NS, mode=mode)
         pending += 1
         if pending == depth:
@@ -52,11 +57,16 @@ def run(n, depth=3):
 
 
 def apply(text):
+    global AHEAD
     opts = dict(DEFAULTS)
+    AHEAD = 0
     for kv in text.split(","):
         if kv:
             k, v = kv.split("=")
-            opts[k] = int(v)
+            if k == "ahead":
+                AHEAD = int(v)
+            else:
+                opts[k] = int(v)
     for k, v in opts.items():
         eng.set_option(k, v)
 
