@@ -1,6 +1,6 @@
 """Would whole steps on alternating streams (no cross-stream event on the critical path) beat carve || expansion of neighbouring
 steps?  Emulated with K independent contexts on one device, each running its steps on ONE stream (overlap=0), the host dealing
-steps round-robin.  usage: python scripts/exp_lanes.py [mode=lut|fused] K[,K..] [depth per context]"""
+steps round-robin.  usage: python scripts/exp_lanes.py [mode=lut|fused] [workload=config5] K[,K..] [depth per context]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -9,13 +9,25 @@ import voxcarve, fixtures_util as fx
 
 mode = "lut"
 args = [a for a in sys.argv[1:]]
-if args and args[0].startswith("mode="):
-    mode = args.pop(0)[5:]
+workload = "real"
+for a in list(args):
+    if a.startswith("mode="):
+        mode = a[5:]; args.remove(a)
+    elif a.startswith("workload="):
+        workload = a[9:]; args.remove(a)
 Ks = [int(x) for x in (args[0] if args else "1,2,3").split(",")]
 depth = int(args[1]) if len(args) > 1 else 1
-cams, masks = fx.golden_cameras(), fx.golden_masks()
-frames = fx.synthetic_frames(4, *masks[0].shape)
-grid = (1024, 1024, 1024)
+if workload == "config5":
+    from voxcarve import synthetic
+    H, W, C = 1080, 1920, 16
+    cams = synthetic.ring_cameras(C, H, W)
+    masks = synthetic.ellipsoid_masks(cams, H, W)
+    frames = synthetic.random_frames(C, H, W)
+    grid = (512, 512, 512)
+else:
+    cams, masks = fx.golden_cameras(), fx.golden_masks()
+    frames = fx.synthetic_frames(4, *masks[0].shape)
+    grid = (1024, 1024, 1024)
 NS = 8
 engs = []
 for k in range(max(Ks)):
@@ -26,7 +38,7 @@ for k in range(max(Ks)):
         e.upload_frame(1, np.roll(frames[1], 3 * s, axis=1), slot=s)
     if mode == "lut":
         e.build_lut()
-    e.set_option("overlap", 0)
+    e.set_option("overlap", int(os.environ.get("LANES_OVERLAP", "0")))
     engs.append(e)
 
 
