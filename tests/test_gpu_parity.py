@@ -173,6 +173,7 @@ def test_every_kernel_family_agrees_with_oracle(eng, seed):
                      {"fused_boxes": 0, "fused_tile": 0}, {"lut_hier": 0}, {"lut_hier": 0, "first_kv": 4}, {"lut_hier": 1, "refine_b": 16, "refine_pair": 0},
                      {"reorder": 0}, {"fused_hier": 0}, {"refine_pair": 0}, {"emit_lanes": 0}, {"emit_busy": 2}, {"emit_busy": 2, "lut_tile": 0, "fused_tile": 0},
                      {"grid_lds_kb": 64}, {"grid_lds_kb": 148, "voxel_pairs": 2}, {"voxel_pairs": 1},     # 1024-thread workgroups, coarse brick grids
+                     {"dbg": 8192}, {"grid_lds_kb": 148, "dbg": 8192}, {"grid_lds_kb": 148, "dbg": 16384},  # every brick listed untested; word level in lockstep
                      {"force_generic": 1}):
             for k, v in opts.items():
                 eng.set_option(k, v)
@@ -187,11 +188,11 @@ def test_every_kernel_family_agrees_with_oracle(eng, seed):
                 assert np.array_equal(eng.fetch_occupancy(), occ), (opts, mode)
                 assert int(np.bitwise_count(eng.pack_entries()[:, 0]).sum()) == want["count"], (opts, mode)
             for k in opts:
-                eng.set_option(k, {"lut_hier": 1, "bricks": 1, "cull": 1, "lut_tile": 1, "fused_tile": 1, "fused_f32box": 1, "fused_boxes": 1, "fused_color_table": 1, "first_kv": 1, "refine_b": 8, "reorder": 1, "fused_hier": 1, "refine_pair": 1, "emit_lanes": 1, "emit_busy": 1, "force_generic": 0, "grid_lds_kb": 0, "voxel_pairs": 0}[k])
+                eng.set_option(k, {"lut_hier": 1, "bricks": 1, "cull": 1, "lut_tile": 1, "fused_tile": 1, "fused_f32box": 1, "fused_boxes": 1, "fused_color_table": 1, "first_kv": 1, "refine_b": 8, "reorder": 1, "fused_hier": 1, "refine_pair": 1, "emit_lanes": 1, "emit_busy": 1, "force_generic": 0, "grid_lds_kb": 0, "voxel_pairs": 0, "dbg": 0}[k])
             if "grid_lds_kb" in opts:
                 eng.touch_masks(0)
     finally:
-        for k, v in {"lut_hier": 1, "bricks": 1, "cull": 1, "lut_tile": 1, "fused_tile": 1, "fused_f32box": 1, "fused_boxes": 1, "fused_color_table": 1, "first_kv": 1, "refine_b": 8, "reorder": 1, "fused_hier": 1, "refine_pair": 1, "emit_lanes": 1, "emit_busy": 1, "force_generic": 0, "grid_lds_kb": 0, "voxel_pairs": 0}.items():
+        for k, v in {"lut_hier": 1, "bricks": 1, "cull": 1, "lut_tile": 1, "fused_tile": 1, "fused_f32box": 1, "fused_boxes": 1, "fused_color_table": 1, "first_kv": 1, "refine_b": 8, "reorder": 1, "fused_hier": 1, "refine_pair": 1, "emit_lanes": 1, "emit_busy": 1, "force_generic": 0, "grid_lds_kb": 0, "voxel_pairs": 0, "dbg": 0}.items():
             eng.set_option(k, v)
     with pytest.raises(Exception):
         eng.set_option("no_such_option", 1)
@@ -369,6 +370,25 @@ def test_config5_shape_16_cameras_1080p(eng):
     want12 = carve_c.carve(*grid, fx.oracle_cams(scams), smasks, sframes, color_cam=5, min_views=12)
     assert eng.carve(mode="fused", color_cam=5, min_views=12) == want12["count"] > want["count"]
     assert np.array_equal(eng.fetch()[0], want12["idx"])
+    # the same inputs on brick-pipeline shapes (ny 256 / 2048): 138 KB of block grids shared by 1 024-thread workgroups, the word
+    # level on the compacted survivors of four bricks (default) or in lockstep (dbg 16384), the brick level testing, listing
+    # everything because told to (dbg 8192) or because the step before listed nine bricks in ten (the later steps of each row)
+    try:
+        for grid in ((36, 256, 40), (8, 2048, 20)):
+            want = carve_c.carve(*grid, fx.oracle_cams(scams), smasks, sframes, color_cam=5)
+            assert want["count"] > 100
+            eng.set_grid(*grid)
+            eng.build_lut()
+            for dbg in (0, 16384, 8192):
+                eng.set_option("dbg", dbg)
+                for step in range(3):
+                    eng.touch_masks(0)
+                    for mode in ("lut", "fused"):
+                        assert eng.carve(mode=mode, color_cam=5) == want["count"], (grid, dbg, step, mode)
+                        idx, rgb, seen = eng.fetch()
+                        assert np.array_equal(idx, want["idx"]) and np.array_equal(rgb[:, ::-1], want["bgr"]) and seen.all(), (grid, dbg, step, mode)
+    finally:
+        eng.set_option("dbg", 0)
 
 
 def test_device_mask_postfilter_matches_restatement(eng, cams, masks):
