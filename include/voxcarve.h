@@ -219,6 +219,11 @@ int vc_mog_create(vc_ctx *ctx, int history, int nmixtures, double background_rat
 int vc_mog_apply(vc_ctx *ctx, uint32_t model, const uint8_t *image, uint32_t H, uint32_t W, double learning_rate, uint8_t *fgmask);
 int vc_mog_state(vc_ctx *ctx, uint32_t model, float *state, uint64_t capacity, uint32_t *H, uint32_t *W, uint32_t *nmixtures, uint32_t *nframes);
 int vc_mog_destroy(vc_ctx *ctx, uint32_t model);
+/* Everything of extract_foreground_mask in front of the contour stage in one call, one copy each way: BGR -> HSV where to_hsv
+ * (:155; the reference always does), the model's apply with `learning_rate` (:158), the 3x3 opening / closing where asked
+ * (:161-168).  bgr uint8 [H,W,3] in, the model's mask uint8 [H,W] out. */
+int vc_foreground_front(vc_ctx *ctx, uint32_t model, const uint8_t *bgr, uint32_t H, uint32_t W, int to_hsv, double learning_rate,
+                        int open, int close, uint8_t *mask);
 
 /* ---- the step after the path: marching cubes over the dense ON/OFF volume -------------------------------
  * Replaces skimage.measure.marching_cubes(voxels_status, 0) of plot_marching_cubes, voxel_reconstruction.py:127-163, whose

@@ -512,6 +512,13 @@ def test_mog_background_model_on_device(eng):
     got = bs.extract_foreground_mask(frames[14], model, 0, 5000, 115, True, True, True, True, engine=eng, contour_stage=keep)
     want = pf.post_filter(keep(fg.pre_filter(ref.apply(fg.bgr_to_hsv(frames[14]), 0), True, True), 0, 0), True, True)
     assert np.array_equal(got, want) and got.any()
+    # (that went through vc_foreground_front: conversion, apply and pre-filter in one call) -- the same as the three calls, learning too
+    for lr, op, cl, hsv in ((0.02, False, True, True), (0, True, False, False), (-1, False, False, True)):
+        src = frames[15] if hsv else fg.bgr_to_hsv(frames[15])
+        one = eng.foreground_front(model._model, src, lr, op, cl, to_hsv=hsv)
+        three = fg.pre_filter(ref.apply(fg.bgr_to_hsv(frames[15]), lr), op, cl)
+        assert np.array_equal(one, three), (lr, op, cl, hsv)
+        assert np.array_equal(model.state()[0].view(np.uint32), ref.state.view(np.uint32))
     from voxcarve._lib import VoxcarveError
     with pytest.raises(VoxcarveError, match="cv2"):           # decoding the reference's background.avi needs cv2: absent here, and says so
         bs.train_MOG_background_model("data/cam1", "background.avi", engine=eng)

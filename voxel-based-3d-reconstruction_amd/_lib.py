@@ -73,6 +73,8 @@ SIGNATURES = {
     "vc_mog_state": (ctypes.c_int, [c_ctx, ctypes.c_uint32, ctypes.POINTER(ctypes.c_float), ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint32),
                                     ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]),
     "vc_mog_destroy": (ctypes.c_int, [c_ctx, ctypes.c_uint32]),
+    "vc_foreground_front": (ctypes.c_int, [c_ctx, ctypes.c_uint32, c_u8p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_double,
+                                           ctypes.c_int, ctypes.c_int, c_u8p]),
     "vc_upload_frame": (ctypes.c_int, [c_ctx, ctypes.c_uint32, ctypes.c_uint32, c_u8p]),
     "vc_build_lut": (ctypes.c_int, [c_ctx]),
     "vc_fetch_lut": (ctypes.c_int, [c_ctx, ctypes.c_uint32, c_i32p]),

@@ -132,10 +132,14 @@ def extract_foreground_mask(image, bg_model, learning_rate=0, figure_threshold=5
     ``engine``: the CarveEngine whose device does the work (default: one on device 0); ``contour_stage``: what stands in for
     ``fill_figures`` (tests; default: the cv2 one)."""
     eng = engine if engine is not None else _default_engine()
-    hsv = eng.bgr_to_hsv(image)
-    model_mask = np.ascontiguousarray(bg_model.apply(hsv, None, learning_rate), dtype=np.uint8)
-    if apply_opening_pre or apply_closing_pre:
-        model_mask = eng.mask_morphology(model_mask, 3, apply_opening_pre, apply_closing_pre)
+    if isinstance(bg_model, BackgroundSubtractorMOG) and bg_model._eng is eng:
+        # the model lives on this device: colour conversion, apply and pre-filter without leaving it
+        model_mask = eng.foreground_front(bg_model._model, image, learning_rate, apply_opening_pre, apply_closing_pre)
+    else:
+        hsv = eng.bgr_to_hsv(image)
+        model_mask = np.ascontiguousarray(bg_model.apply(hsv, None, learning_rate), dtype=np.uint8)
+        if apply_opening_pre or apply_closing_pre:
+            model_mask = eng.mask_morphology(model_mask, 3, apply_opening_pre, apply_closing_pre)
     figures = (contour_stage or fill_figures)(model_mask, figure_threshold, figure_inner_threshold)
     if apply_opening_post or apply_closing_post:
         figures = eng.mask_morphology(figures, 2, apply_opening_post, apply_closing_post)

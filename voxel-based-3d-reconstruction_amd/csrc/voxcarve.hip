@@ -2093,6 +2093,8 @@ int vc_fetch_mesh(vc_ctx *ctx, float *verts, uint32_t *faces)
 }
 
 // ---- the step before the path, its data-parallel part (reference background_subtraction.py:153-168) ----
+static int hsv_tables(vc_ctx *ctx);
+
 int vc_bgr_to_hsv(vc_ctx *ctx, const uint8_t *bgr, uint32_t H, uint32_t W, uint8_t *hsv)
 {
     if (!ctx || !bgr || !hsv) return VC_ERR_ARG;
@@ -2100,17 +2102,7 @@ int vc_bgr_to_hsv(vc_ctx *ctx, const uint8_t *bgr, uint32_t H, uint32_t W, uint8
     VC_HIP(ctx, hipSetDevice(ctx->device));
     const size_t npix = (size_t)H * W;
     hipStream_t st = ctx->stream_up;
-    if (!ctx->d_hsvdiv.ptr) {
-        // as OpenCV builds them (color_hsv: RGB2HSV_b): saturate_cast<int>(double) = round half to even
-        int32_t t[512];
-        t[0] = t[256] = 0;
-        for (int i = 1; i < 256; ++i) {
-            t[i] = (int32_t)std::nearbyint((double)(255 << kHsvShift) / (1.0 * i));
-            t[256 + i] = (int32_t)std::nearbyint((double)(180 << kHsvShift) / (6.0 * i));
-        }
-        VC_TRY(ensure(ctx, ctx->d_hsvdiv, 512));
-        VC_HIP(ctx, hipMemcpy(ctx->d_hsvdiv.ptr, t, sizeof t, hipMemcpyHostToDevice));
-    }
+    VC_TRY(hsv_tables(ctx));
     VC_TRY(ensure(ctx, ctx->d_fg, npix * 6 + 64));
     uint8_t *d_in = ctx->d_fg.ptr, *d_out = d_in + npix * 3;
     VC_HIP(ctx, hipMemcpyAsync(d_in, bgr, npix * 3, hipMemcpyHostToDevice, st));
@@ -2184,13 +2176,10 @@ int vc_mog_destroy(vc_ctx *ctx, uint32_t model)
     return VC_OK;
 }
 
-int vc_mog_apply(vc_ctx *ctx, uint32_t model, const uint8_t *image, uint32_t H, uint32_t W, double learning_rate, uint8_t *fgmask)
+// One frame through a background model: d_img (device, [H W 3]) -> d_mask (device, [H W]) on the upload stream.
+static int mog_enqueue(vc_ctx *ctx, uint32_t model, const uint8_t *d_img, uint32_t H, uint32_t W, double learning_rate, uint8_t *d_mask)
 {
-    if (!ctx || !image || !fgmask) return VC_ERR_ARG;
-    if (model >= VC_MAX_MOG_MODELS || !ctx->mog[model].used) return fail(ctx, VC_ERR_ARG, "no background model %u", model);
-    if (H == 0 || W == 0 || (uint64_t)H * W > 0x0fffffffull) return fail(ctx, VC_ERR_ARG, "image size %u x %u", H, W);
     vc_ctx::MogModel &m = ctx->mog[model];
-    VC_HIP(ctx, hipSetDevice(ctx->device));
     const size_t npix = (size_t)H * W;
     hipStream_t st = ctx->stream_up;
     // apply(): the model starts over on its first frame, on a learning rate >= 1 and when the image size changes
@@ -2209,12 +2198,72 @@ int vc_mog_apply(vc_ctx *ctx, uint32_t model, const uint8_t *image, uint32_t H, 
     p.var0 = (float)(default_noise_sigma * default_noise_sigma * 4);
     p.minVar = (float)(m.noise_sigma * m.noise_sigma);
     p.K = (uint32_t)m.nmixtures; p.npix = (uint32_t)npix;
+    hipLaunchKernelGGL(k_mog_apply, dim3((uint32_t)((npix + 255) / 256)), dim3(256), 0, st, d_img, d_mask, m.state.ptr, p);
+    VC_HIP(ctx, hipGetLastError());
+    return VC_OK;
+}
+
+static int hsv_tables(vc_ctx *ctx)
+{
+    if (ctx->d_hsvdiv.ptr) return VC_OK;
+    // as OpenCV builds them (color_hsv: RGB2HSV_b): saturate_cast<int>(double) = round half to even
+    int32_t t[512];
+    t[0] = t[256] = 0;
+    for (int i = 1; i < 256; ++i) {
+        t[i] = (int32_t)std::nearbyint((double)(255 << kHsvShift) / (1.0 * i));
+        t[256 + i] = (int32_t)std::nearbyint((double)(180 << kHsvShift) / (6.0 * i));
+    }
+    VC_TRY(ensure(ctx, ctx->d_hsvdiv, 512));
+    VC_HIP(ctx, hipMemcpy(ctx->d_hsvdiv.ptr, t, sizeof t, hipMemcpyHostToDevice));
+    return VC_OK;
+}
+
+int vc_mog_apply(vc_ctx *ctx, uint32_t model, const uint8_t *image, uint32_t H, uint32_t W, double learning_rate, uint8_t *fgmask)
+{
+    if (!ctx || !image || !fgmask) return VC_ERR_ARG;
+    if (model >= VC_MAX_MOG_MODELS || !ctx->mog[model].used) return fail(ctx, VC_ERR_ARG, "no background model %u", model);
+    if (H == 0 || W == 0 || (uint64_t)H * W > 0x0fffffffull) return fail(ctx, VC_ERR_ARG, "image size %u x %u", H, W);
+    VC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t npix = (size_t)H * W;
+    hipStream_t st = ctx->stream_up;
     VC_TRY(ensure(ctx, ctx->d_fg, npix * 6 + 64));
     uint8_t *d_in = ctx->d_fg.ptr, *d_out = d_in + npix * 3;
     VC_HIP(ctx, hipMemcpyAsync(d_in, image, npix * 3, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_mog_apply, dim3((uint32_t)((npix + 255) / 256)), dim3(256), 0, st, (const uint8_t *)d_in, d_out, m.state.ptr, p);
-    VC_HIP(ctx, hipGetLastError());
+    VC_TRY(mog_enqueue(ctx, model, d_in, H, W, learning_rate, d_out));
     VC_HIP(ctx, hipMemcpyAsync(fgmask, d_out, npix, hipMemcpyDeviceToHost, st));
+    VC_HIP(ctx, hipStreamSynchronize(st));
+    return VC_OK;
+}
+
+int vc_foreground_front(vc_ctx *ctx, uint32_t model, const uint8_t *bgr, uint32_t H, uint32_t W, int to_hsv, double learning_rate,
+                        int open, int close, uint8_t *mask)
+{
+    if (!ctx || !bgr || !mask) return VC_ERR_ARG;
+    if (model >= VC_MAX_MOG_MODELS || !ctx->mog[model].used) return fail(ctx, VC_ERR_ARG, "no background model %u", model);
+    if (H == 0 || W == 0 || (uint64_t)H * W > 0x0fffffffull) return fail(ctx, VC_ERR_ARG, "image size %u x %u", H, W);
+    VC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t npix = (size_t)H * W;
+    hipStream_t st = ctx->stream_up;
+    VC_TRY(hsv_tables(ctx));
+    VC_TRY(ensure(ctx, ctx->d_fg, npix * 8 + 64));
+    uint8_t *d_in = ctx->d_fg.ptr, *d_hsv = d_in + npix * 3, *a = d_hsv + npix * 3, *b = a + npix;
+    VC_HIP(ctx, hipMemcpyAsync(d_in, bgr, npix * 3, hipMemcpyHostToDevice, st));
+    const dim3 g((uint32_t)((npix + 255) / 256)), blk(256);
+    if (to_hsv) {
+        hipLaunchKernelGGL(k_bgr2hsv, g, blk, 0, st, (const uint8_t *)d_in, d_hsv, (uint32_t)npix, (const int32_t *)ctx->d_hsvdiv.ptr,
+                           (const int32_t *)(ctx->d_hsvdiv.ptr + 256));
+        VC_HIP(ctx, hipGetLastError());
+    }
+    VC_TRY(mog_enqueue(ctx, model, to_hsv ? d_hsv : d_in, H, W, learning_rate, a));
+    auto pass = [&](bool dilate) {
+        if (dilate) hipLaunchKernelGGL(k_morph3x3<true>, g, blk, 0, st, (const uint8_t *)a, b, H, W);
+        else hipLaunchKernelGGL(k_morph3x3<false>, g, blk, 0, st, (const uint8_t *)a, b, H, W);
+        uint8_t *t = a; a = b; b = t;
+    };
+    if (open) { pass(false); pass(true); }
+    if (close) { pass(true); pass(false); }
+    VC_HIP(ctx, hipGetLastError());
+    VC_HIP(ctx, hipMemcpyAsync(mask, a, npix, hipMemcpyDeviceToHost, st));
     VC_HIP(ctx, hipStreamSynchronize(st));
     return VC_OK;
 }

@@ -174,6 +174,18 @@ class CarveEngine:
             self._check(self._L.vc_mog_state(self._ctx, int(model), _ptr(state, ctypes.c_float), state.size, None, None, None, None), "vc_mog_state")
         return state, (H.value, W.value), nf.value
 
+    def foreground_front(self, model, image, learning_rate=0, opening=False, closing=False, to_hsv=True):
+        """BGR -> HSV, the model's apply, 3x3 open / close: extract_foreground_mask up to its contour stage, one call
+        (background_subtraction.py:155-168)."""
+        a = np.ascontiguousarray(image, dtype=np.uint8)
+        if a.ndim != 3 or a.shape[2] != 3:
+            raise ValueError("image shape %s, expected [H, W, 3]" % (a.shape,))
+        out = np.empty(a.shape[:2], dtype=np.uint8)
+        self._check(self._L.vc_foreground_front(self._ctx, int(model), _ptr(a, ctypes.c_uint8), a.shape[0], a.shape[1], int(bool(to_hsv)),
+                                                float(learning_rate), int(bool(opening)), int(bool(closing)), _ptr(out, ctypes.c_uint8)),
+                    "vc_foreground_front")
+        return out
+
     def mog_destroy(self, model):
         self._check(self._L.vc_mog_destroy(self._ctx, int(model)), "vc_mog_destroy")
 
