@@ -1017,7 +1017,7 @@ int enqueue_expand(vc_ctx *ctx, hipStream_t st, const uint64_t *d_entries, uint6
         if (st != ctx->stream) VC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     const dim3 grid((ngroups + 3) / 4), block(kBlock);
-    hipLaunchKernelGGL(k_count_entries, grid, block, 0, st, d_entries, M, ngroups, ctx->d_ycnt.ptr, chunk);
+    hipLaunchKernelGGL(k_count_entries, chunk == 16u ? dim3((ngroups + 15) / 16) : grid, block, 0, st, d_entries, M, ngroups, ctx->d_ycnt.ptr, chunk);
     VC_HIP(ctx, hipGetLastError());
     VC_TRY(scan_counts(ctx, st, ctx->d_ycnt.ptr, ngroups, ctx->d_yoff.ptr, ctx->d_ybsum.ptr, ctx->d_yboff.ptr, h_total));
     if (S_hint == 0) {
