@@ -1601,8 +1601,8 @@ __global__ __launch_bounds__(kBlock) void k_voxel_words(const CarveParams p, con
     const ShardView sv = shard_view(bl.counters + (bl.parity * 3 + 2) * kShards * kShardStride, B, lane);    // in batches of B words, per shard
     const uint32_t nbatch = sv.total;
     if (blockIdx.x == 0 && threadIdx.x == 0) bl.host_counts[2] = nbatch * B;
-    const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
-    const uint32_t nwaves = gridDim.x * (kBlock / 64);
+    const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const uint32_t nwaves = gridDim.x * (blockDim.x / 64);
     const uint32_t qpl = p.nx >> 2;
     uint64_t nstat = 0;
     // lane b < B fetches entry b of a batch; everybody gets them by cross-lane reads.  A wave that takes several batches has the
@@ -1709,8 +1709,8 @@ __global__ __launch_bounds__(kBlock) void k_assemble(const CarveParams p, const 
     const ShardView sv = shard_view(bl.counters + (bl.parity * 3 + 1) * kShards * kShardStride, 1, lane);
     const uint32_t ncols = sv.total;
     if (blockIdx.x == 0 && threadIdx.x == 0) bl.host_counts[1] = ncols;
-    const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
-    const uint32_t nwaves = gridDim.x * (kBlock / 64);
+    const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const uint32_t nwaves = gridDim.x * (blockDim.x / 64);
     const uint32_t qpl = p.nx >> 2, nzl = (uint32_t)(p.n / ((uint64_t)p.nx * p.ny));
     const uint32_t nunits = ncols * 16u;
     const uint32_t nw = p.nbrick_pad >> 6;

@@ -650,10 +650,14 @@ int launch_bricks(vc_ctx *ctx, CarveParams &p, size_t lds, uint32_t ngroups)
     // per round: 0.1368 -> 0.1345 ms per step at 1024^3 x 4; 16: 0.147), 1 where it is long (projection 0.175 -> 0.19, one camera per round 0.30 -> 0.32)
     const uint32_t vb = ctx->voxel_batches ? (uint32_t)ctx->voxel_batches : (LUT && pairs ? 8u : 1u);
     const dim3 vgrid(sized(k_words, (uint64_t)p.nbrick_pad * 4, (uint64_t)p.nbrick_pad * 64, (pairs ? 32u : 64u) * vb));
-    if (pairs) VC_KLAUNCH(VC_K_VOXEL_WORDS, (k_voxel_words<LUT, true>), vgrid, block, 0, ctx->stream, p, bl);
-    else VC_KLAUNCH(VC_K_VOXEL_WORDS, (k_voxel_words<LUT, false>), vgrid, block, 0, ctx->stream, p, bl);
-    VC_KLAUNCH(VC_K_ASSEMBLE, k_assemble, dim3(sized(k_cols == 0xffffffffu ? k_cols : k_cols * 16u, (uint64_t)ncolumns * 4, (uint64_t)ncolumns * 16, 4)),
-                       block, 0, ctx->stream, p, bl);
+    // one wave per workgroup for the two list-driven kernels that need no LDS: a workgroup of four has to find four free wave slots on one
+    // compute unit at once, beside an expansion that refills every slot as it frees (the scans' lesson, in small: step -1.3 %)
+    const uint32_t wpw = 1u;
+    const dim3 vgrid2(vgrid.x * (4u / wpw)), sblock(64u * wpw);
+    if (pairs) VC_KLAUNCH(VC_K_VOXEL_WORDS, (k_voxel_words<LUT, true>), vgrid2, sblock, 0, ctx->stream, p, bl);
+    else VC_KLAUNCH(VC_K_VOXEL_WORDS, (k_voxel_words<LUT, false>), vgrid2, sblock, 0, ctx->stream, p, bl);
+    VC_KLAUNCH(VC_K_ASSEMBLE, k_assemble, dim3(sized(k_cols == 0xffffffffu ? k_cols : k_cols * 16u, (uint64_t)ncolumns * 4, (uint64_t)ncolumns * 16, 4) * (4u / wpw)),
+                       sblock, 0, ctx->stream, p, bl);
     VC_HIP(ctx, hipGetLastError());
     return VC_OK;
 }
