@@ -1275,7 +1275,8 @@ __global__ __launch_bounds__(kWideBlock) void k_cull_bricks(const CarveParams p,
     if (staged) stage_grids(s_grid, gsrc);
     __shared__ uint32_t s_order[kMaxCameras];
     stage_order(p.counts, p.C, s_order);
-    if (blockIdx.x == 0 && threadIdx.x < 3 * kShards) bl.counters[((bl.parity ^ 1u) * 3 * kShards + threadIdx.x) * kShardStride] = 0;
+    if (blockIdx.x == 0)                                             // (any workgroup size: 192 counters)
+        for (uint32_t i = threadIdx.x; i < 3 * kShards; i += blockDim.x) bl.counters[((bl.parity ^ 1u) * 3 * kShards + i) * kShardStride] = 0;
     uint32_t *cnt = bl.counters + bl.parity * 3 * kShards * kShardStride;
     const uint32_t gshift = staged ? hdr_u32(s_grid, kHdrShift) : 0u;
     const uint32_t lane = threadIdx.x & 63u;
